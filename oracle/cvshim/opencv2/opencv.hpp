@@ -1,0 +1,600 @@
+// cv-shim: the *minimum* of the OpenCV API that libcimbar's frame codec touches, so that the
+// reference's own sources (Decoder.h, CimbReader.cpp, CimbDecoder.cpp, Encoder.h, CimbWriter.cpp,
+// Common.cpp, ...) compile UNMODIFIED from /root/reference into oracle/_ref/libcimbar_ref.so.
+//
+// TEST INFRASTRUCTURE ONLY. Nothing in the product (libcimbar_amd/) includes this file.
+//
+// OpenCV itself is not in /root/reference (external system dependency, CMakeLists.txt:38) and is not
+// installed in the build container, so every arithmetic rule below is a restatement of OpenCV 4.5.x's
+// published behaviour and is marked [assumed-OpenCV]:
+//   * cvtColor RGB2GRAY (8u): (R*9798 + G*19235 + B*3735 + (1<<14)) >> 15      (color_rgb.simd.hpp, RGB2Gray<uchar>)
+//   * adaptiveThreshold MEAN_C/BINARY: boxFilter(ksize, normalize, BORDER_REPLICATE) to 8u through the
+//     ushort column-sum path ((sum + divDelta) * divScale >> 23), then dst = src > mean ? 255 : 0
+//     (thresh.cpp adaptiveThreshold, box_filter.simd.hpp ColumnSum<ushort,uchar>)
+//   * filter2D 8u->8u with a float kernel: float accumulation, BORDER_REFLECT_101, saturate_cast<uchar>(cvRound)
+//   * mean(): per-channel double sum / count
+//   * Matx small-matrix ops in the element type, textbook order (matx.hpp MatxMulOp, Matx_FastInvOp<3,3>)
+//   * Mat*Mat for CV_32F: double accumulation, cast to float (matmul.simd.hpp GEMMSingleMul<float,double>)
+//   * invert(DECOMP_SVD): one-sided Jacobi SVD (lapack.cpp JacobiSVDImpl_<float>) + SVBkSb back-substitution
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+typedef unsigned char uchar;
+
+#define CV_VERSION_MAJOR 4
+#define CV_8U 0
+#define CV_32F 5
+#define CV_CN_SHIFT 3
+#define CV_MAT_DEPTH(t) ((t) & 7)
+#define CV_MAT_CN(t) ((((t) >> CV_CN_SHIFT) & 63) + 1)
+#define CV_MAKETYPE(depth, cn) (CV_MAT_DEPTH(depth) + (((cn)-1) << CV_CN_SHIFT))
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
+#define CV_8UC4 CV_MAKETYPE(CV_8U, 4)
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+
+namespace cv {
+
+enum { COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4, COLOR_RGBA2RGB = 1, COLOR_RGB2GRAY = 7 };
+enum { ADAPTIVE_THRESH_MEAN_C = 0 };
+enum { THRESH_BINARY = 0 };
+enum { DECOMP_LU = 0, DECOMP_SVD = 1 };
+enum AccessFlag { ACCESS_READ = 1 << 24, ACCESS_RW = 3 << 24 };
+
+static inline int cvRound(double v) { return (int)lrint(v); }   // round-half-even under the default FP mode
+static inline int cvFloor(double v) { return (int)std::floor(v); }
+static inline uchar saturate_u8(int v) { return (uchar)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} };
+struct Point { int x = 0, y = 0; Point() {} Point(int x_, int y_) : x(x_), y(y_) {} };
+struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+
+struct Scalar
+{
+	double val[4] = {0, 0, 0, 0};
+	Scalar() {}
+	Scalar(double a, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+	double& operator[](int i) { return val[i]; }
+	const double& operator[](int i) const { return val[i]; }
+};
+
+struct Vec3b
+{
+	uchar val[3] = {0, 0, 0};
+	Vec3b() {}
+	Vec3b(uchar a, uchar b, uchar c) { val[0] = a; val[1] = b; val[2] = c; }
+	Vec3b(std::initializer_list<int> l) { int i = 0; for (int v : l) { if (i < 3) val[i++] = (uchar)v; } }
+	uchar& operator[](int i) { return val[i]; }
+	const uchar& operator[](int i) const { return val[i]; }
+	bool operator==(const Vec3b& o) const { return val[0] == o.val[0] && val[1] == o.val[1] && val[2] == o.val[2]; }
+	bool operator!=(const Vec3b& o) const { return !(*this == o); }
+};
+
+// ---------------------------------------------------------------- Matx (small fixed matrices, element-type arithmetic)
+template <typename T, int M, int N>
+struct Matx
+{
+	T val[M * N];
+	Matx() { for (int i = 0; i < M * N; ++i) val[i] = T(0); }
+	Matx(T a, T b, T c) { static_assert(M * N == 3, ""); val[0] = a; val[1] = b; val[2] = c; }
+	Matx(T a, T b, T c, T d, T e, T f, T g, T h, T i)
+	{
+		static_assert(M * N == 9, "");
+		val[0] = a; val[1] = b; val[2] = c; val[3] = d; val[4] = e; val[5] = f; val[6] = g; val[7] = h; val[8] = i;
+	}
+	T& operator()(int i, int j) { return val[i * N + j]; }
+	const T& operator()(int i, int j) const { return val[i * N + j]; }
+	T& operator()(int i) { return val[i]; }
+	const T& operator()(int i) const { return val[i]; }
+
+	static Matx diag(const Matx<T, M, 1>& d)
+	{
+		Matx r;
+		for (int i = 0; i < M; ++i) r(i, i) = d.val[i];
+		return r;
+	}
+	Matx div(const Matx& o) const
+	{
+		Matx r;
+		for (int i = 0; i < M * N; ++i) r.val[i] = val[i] / o.val[i];   // matx.hpp: Matx::div -> element-wise a/b
+		return r;
+	}
+	// matx.hpp Matx_FastInvOp<_Tp,3,3>: closed form through the determinant, all in _Tp
+	Matx inv(int = DECOMP_LU) const
+	{
+		static_assert(M == 3 && N == 3, "shim: only 3x3 inv");
+		const Matx& a = *this;
+		Matx b;
+		T d = (T)(a(0,0) * (a(1,1) * a(2,2) - a(2,1) * a(1,2)) - a(0,1) * (a(1,0) * a(2,2) - a(2,0) * a(1,2)) +
+		          a(0,2) * (a(1,0) * a(2,1) - a(2,0) * a(1,1)));
+		if (d == 0) return b;
+		d = 1 / d;
+		b(0,0) = (a(1,1) * a(2,2) - a(1,2) * a(2,1)) * d;
+		b(0,1) = (a(0,2) * a(2,1) - a(0,1) * a(2,2)) * d;
+		b(0,2) = (a(0,1) * a(1,2) - a(0,2) * a(1,1)) * d;
+		b(1,0) = (a(1,2) * a(2,0) - a(1,0) * a(2,2)) * d;
+		b(1,1) = (a(0,0) * a(2,2) - a(0,2) * a(2,0)) * d;
+		b(1,2) = (a(0,2) * a(1,0) - a(0,0) * a(1,2)) * d;
+		b(2,0) = (a(1,0) * a(2,1) - a(1,1) * a(2,0)) * d;
+		b(2,1) = (a(0,1) * a(2,0) - a(0,0) * a(2,1)) * d;
+		b(2,2) = (a(0,0) * a(1,1) - a(0,1) * a(1,0)) * d;
+		return b;
+	}
+};
+
+// matx.hpp MatxMulOp: s = 0; for k: s += a(i,k)*b(k,j), in the element type
+template <typename T, int M, int L, int N>
+inline Matx<T, M, N> operator*(const Matx<T, M, L>& a, const Matx<T, L, N>& b)
+{
+	Matx<T, M, N> c;
+	for (int i = 0; i < M; ++i)
+		for (int j = 0; j < N; ++j)
+		{
+			T s = 0;
+			for (int k = 0; k < L; ++k) s += a(i, k) * b(k, j);
+			c(i, j) = s;
+		}
+	return c;
+}
+
+// ---------------------------------------------------------------- Mat
+template <typename T> class MatIterator_;
+template <typename T> class Mat_;
+template <typename T> class MatCommaInitializer_;
+
+class Mat
+{
+public:
+	int rows = 0, cols = 0, dims = 2;
+	uchar* data = nullptr;
+	size_t step = 0;   // bytes per row
+
+	Mat() {}
+	Mat(int r, int c, int type) { create(r, c, type); }
+	Mat(int r, int c, int type, const Scalar& s) { create(r, c, type); fill(s); }
+	Mat(int r, int c, int type, void* ext, size_t stp = 0)
+		: rows(r), cols(c), data((uchar*)ext), _type(type)
+	{
+		step = stp ? stp : (size_t)c * elemSize();
+	}
+	template <typename T, int M, int N>
+	explicit Mat(const Matx<T, M, N>& m)
+	{
+		static_assert(sizeof(T) == 4, "shim: float Matx only");
+		create(M, N, CV_32F);
+		std::memcpy(data, m.val, sizeof(T) * M * N);
+	}
+
+	static Mat ones(int r, int c, int type)
+	{
+		Mat m(r, c, type);
+		if (CV_MAT_DEPTH(type) == CV_32F) for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m.ptr<float>(i)[j] = 1.f;
+		else m.fill(Scalar(1, 1, 1, 1));
+		return m;
+	}
+
+	void create(int r, int c, int type)
+	{
+		if (r == rows && c == cols && type == _type && data && isContinuous()) return;
+		rows = r; cols = c; _type = type;
+		step = (size_t)c * elemSize();
+		_buf = std::shared_ptr<uchar>(new uchar[std::max<size_t>(step * (size_t)r, 1)], std::default_delete<uchar[]>());
+		data = _buf.get();
+	}
+
+	int type() const { return _type; }
+	int depth() const { return CV_MAT_DEPTH(_type); }
+	int channels() const { return CV_MAT_CN(_type); }
+	size_t elemSize() const { return (size_t)channels() * (depth() == CV_32F ? 4 : 1); }
+	bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+	bool isContinuous() const { return step == (size_t)cols * elemSize() || rows <= 1; }
+	size_t total() const { return (size_t)rows * cols; }
+
+	template <typename T> T* ptr(int r = 0) { return (T*)(data + (size_t)r * step); }
+	template <typename T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }
+	template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
+	template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+
+	Mat operator()(const Rect& r) const
+	{
+		Mat m;
+		m.rows = r.height; m.cols = r.width; m._type = _type; m.step = step; m._buf = _buf;
+		m.data = data + (size_t)r.y * step + (size_t)r.x * elemSize();
+		return m;
+	}
+
+	Mat clone() const
+	{
+		Mat m(rows, cols, _type);
+		for (int i = 0; i < rows; ++i) std::memcpy(m.ptr<uchar>(i), ptr<uchar>(i), (size_t)cols * elemSize());
+		return m;
+	}
+	void copyTo(Mat& dst) const
+	{
+		if (dst.rows != rows || dst.cols != cols || dst._type != _type || !dst.data) dst.create(rows, cols, _type);
+		for (int i = 0; i < rows; ++i) std::memmove(dst.ptr<uchar>(i), ptr<uchar>(i), (size_t)cols * elemSize());
+	}
+	void copyTo(Mat&& dst) const { Mat& d = dst; copyTo(d); }   // ROI temporaries: img.copyTo(canvas(Rect))
+
+	void push_back(const Mat& row)
+	{
+		Mat m(rows + row.rows, row.cols, row._type);
+		for (int i = 0; i < rows; ++i) std::memcpy(m.ptr<uchar>(i), ptr<uchar>(i), (size_t)cols * elemSize());
+		for (int i = 0; i < row.rows; ++i) std::memcpy(m.ptr<uchar>(rows + i), row.ptr<uchar>(i), (size_t)row.cols * row.elemSize());
+		*this = m;
+	}
+
+	template <typename T> MatIterator_<T> begin();
+	template <typename T> MatIterator_<T> end();
+
+	template <typename T, int M, int N>
+	operator Matx<T, M, N>() const
+	{
+		Matx<T, M, N> r;
+		for (int i = 0; i < M; ++i) for (int j = 0; j < N; ++j) r(i, j) = ptr<T>(i)[j];
+		return r;
+	}
+
+protected:
+	void fill(const Scalar& s)
+	{
+		for (int i = 0; i < rows; ++i)
+		{
+			uchar* p = ptr<uchar>(i);
+			for (int j = 0; j < cols; ++j)
+				for (int c = 0; c < channels(); ++c) p[j * channels() + c] = saturate_u8(cvRound(s[c]));
+		}
+	}
+	int _type = 0;
+	std::shared_ptr<uchar> _buf;
+};
+
+class UMat : public Mat
+{
+public:
+	UMat() {}
+	UMat(const Mat& m) : Mat(m) {}
+	Mat getMat(AccessFlag) const { return *this; }
+};
+
+template <typename T>
+class MatIterator_
+{
+public:
+	MatIterator_(Mat* m, size_t pos) : _m(m), _pos(pos) {}
+	T& operator*() { return _m->ptr<T>((int)(_pos / _m->cols))[_pos % _m->cols]; }
+	MatIterator_& operator++() { ++_pos; return *this; }
+	bool operator!=(const MatIterator_& o) const { return _pos != o._pos; }
+	bool operator==(const MatIterator_& o) const { return _pos == o._pos; }
+protected:
+	Mat* _m;
+	size_t _pos;
+};
+template <typename T> inline MatIterator_<T> Mat::begin() { return MatIterator_<T>(this, 0); }
+template <typename T> inline MatIterator_<T> Mat::end() { return MatIterator_<T>(this, total()); }
+
+template <typename T>
+class Mat_ : public Mat
+{
+public:
+	Mat_() {}
+	Mat_(int r, int c) : Mat(r, c, CV_32F) { static_assert(sizeof(T) == 4, "shim: Mat_<float> only"); }
+};
+
+template <typename T>
+class MatCommaInitializer_
+{
+public:
+	MatCommaInitializer_(const Mat_<T>& m, T first) : _m(m), _idx(0) { put(first); }
+	template <typename V> MatCommaInitializer_& operator,(V v) { put((T)v); return *this; }
+	operator Mat() const { return _m; }
+	operator Mat_<T>() const { return _m; }
+protected:
+	void put(T v) { _m.template ptr<T>((int)(_idx / _m.cols))[_idx % _m.cols] = v; ++_idx; }
+	Mat_<T> _m;
+	size_t _idx;
+};
+template <typename T, typename V>
+inline MatCommaInitializer_<T> operator<<(const Mat_<T>& m, V v) { return MatCommaInitializer_<T>(m, (T)v); }
+
+// ---------------------------------------------------------------- imgproc subset
+// [assumed-OpenCV] color_rgb.simd.hpp RGB2Gray<uchar>: 15-bit fixed point, R2Y=9798 G2Y=19235 B2Y=3735
+inline void cvtColor(const Mat& src_, Mat& dst, int code)
+{
+	Mat src = src_;   // keeps the buffer alive for in-place calls
+	if (code == COLOR_RGB2GRAY)
+	{
+		Mat out(src.rows, src.cols, CV_8UC1);
+		int cn = src.channels();
+		for (int y = 0; y < src.rows; ++y)
+		{
+			const uchar* s = src.ptr<uchar>(y);
+			uchar* d = out.ptr<uchar>(y);
+			for (int x = 0; x < src.cols; ++x, s += cn)
+				d[x] = (uchar)((s[0] * 9798 + s[1] * 19235 + s[2] * 3735 + (1 << 14)) >> 15);
+		}
+		dst = out;
+	}
+	else if (code == COLOR_RGBA2RGB)
+	{
+		Mat out(src.rows, src.cols, CV_8UC3);
+		for (int y = 0; y < src.rows; ++y)
+		{
+			const uchar* s = src.ptr<uchar>(y);
+			uchar* d = out.ptr<uchar>(y);
+			for (int x = 0; x < src.cols; ++x) { d[3*x] = s[4*x]; d[3*x+1] = s[4*x+1]; d[3*x+2] = s[4*x+2]; }
+		}
+		dst = out;
+	}
+	else if (code == COLOR_BGR2RGB)
+	{
+		Mat out(src.rows, src.cols, CV_8UC3);
+		for (int y = 0; y < src.rows; ++y)
+		{
+			const uchar* s = src.ptr<uchar>(y);
+			uchar* d = out.ptr<uchar>(y);
+			for (int x = 0; x < src.cols; ++x) { d[3*x] = s[3*x+2]; d[3*x+1] = s[3*x+1]; d[3*x+2] = s[3*x]; }
+		}
+		dst = out;
+	}
+	else
+	{
+		std::cerr << "cv-shim: unsupported cvtColor code " << code << std::endl;
+		std::abort();
+	}
+}
+
+inline void resize(const Mat&, Mat&, Size)
+{
+	// only reached for tiles larger than 8x8 (average_hash.h:24); mode-B tiles are 8x8
+	std::cerr << "cv-shim: resize() is not part of the mode-B hot path" << std::endl;
+	std::abort();
+}
+
+// [assumed-OpenCV] filter2D, ddepth=-1, 8u, float kernel, anchor centre, delta 0, BORDER_REFLECT_101;
+// accumulation in float over the non-zero taps, then saturate_cast<uchar>(float) = clamp(cvRound(v)).
+inline void filter2D(const Mat& src_, Mat& dst, int, const Mat& kernel)
+{
+	Mat src = src_.clone();
+	Mat out(src.rows, src.cols, src.type());
+	int kh = kernel.rows, kw = kernel.cols, ay = kh / 2, ax = kw / 2;
+	auto refl = [](int p, int n) { if (p < 0) p = -p; if (p >= n) p = 2 * n - 2 - p; return p; };
+	for (int y = 0; y < src.rows; ++y)
+		for (int x = 0; x < src.cols; ++x)
+		{
+			float acc = 0.f;
+			for (int i = 0; i < kh; ++i)
+				for (int j = 0; j < kw; ++j)
+				{
+					float k = kernel.ptr<float>(i)[j];
+					if (k == 0.f) continue;
+					acc += k * (float)src.ptr<uchar>(refl(y + i - ay, src.rows))[refl(x + j - ax, src.cols)];
+				}
+			out.ptr<uchar>(y)[x] = saturate_u8(cvRound(acc));
+		}
+	dst = out;
+}
+
+// [assumed-OpenCV] thresh.cpp adaptiveThreshold(MEAN_C, THRESH_BINARY): mean = boxFilter 8u->8u
+// (BORDER_REPLICATE), ColumnSum<ushort,uchar> normalisation: d=ksize^2, scalef=(1<<23)/d,
+// divScale=floor(scalef), divDelta=d/2 (+1 if frac<0.5, else divScale+1); dst = (src - mean > -ceil(C)) ? maxval : 0
+inline void adaptiveThreshold(const Mat& src_, Mat& dst, double maxval, int, int, int blockSize, double C)
+{
+	Mat src = src_.clone();
+	Mat out(src.rows, src.cols, CV_8UC1);
+	const int r = blockSize / 2, d = blockSize * blockSize, SHIFT = 23;
+	double scalef = ((double)(1 << SHIFT)) / d;
+	int divScale = cvFloor(scalef);
+	scalef -= divScale;
+	int divDelta = d / 2;
+	if (scalef < 0.5) divDelta++; else divScale++;
+	int idelta = (int)std::ceil(C);
+	auto clampi = [](int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); };
+	std::vector<int> rowsum((size_t)src.rows * src.cols);
+	for (int y = 0; y < src.rows; ++y)
+	{
+		const uchar* s = src.ptr<uchar>(y);
+		for (int x = 0; x < src.cols; ++x)
+		{
+			int acc = 0;
+			for (int k = -r; k <= r; ++k) acc += s[clampi(x + k, src.cols)];
+			rowsum[(size_t)y * src.cols + x] = acc;
+		}
+	}
+	for (int y = 0; y < src.rows; ++y)
+		for (int x = 0; x < src.cols; ++x)
+		{
+			int acc = 0;
+			for (int k = -r; k <= r; ++k) acc += rowsum[(size_t)clampi(y + k, src.rows) * src.cols + x];
+			int mean = (int)(((unsigned)(acc + divDelta) * (unsigned)divScale) >> SHIFT);
+			int v = src.ptr<uchar>(y)[x];
+			out.ptr<uchar>(y)[x] = (v - mean > -idelta) ? saturate_u8(cvRound(maxval)) : 0;
+		}
+	dst = out;
+}
+
+// [assumed-OpenCV] mean(): double sum per channel / pixel count
+inline Scalar mean(const Mat& m)
+{
+	Scalar s;
+	int cn = m.channels();
+	for (int y = 0; y < m.rows; ++y)
+	{
+		const uchar* p = m.ptr<uchar>(y);
+		for (int x = 0; x < m.cols; ++x)
+			for (int c = 0; c < cn && c < 4; ++c) s[c] += p[x * cn + c];
+	}
+	double n = (double)m.total();
+	if (n > 0) for (int c = 0; c < 4; ++c) s[c] /= n;
+	return s;
+}
+
+inline void transpose(const Mat& src_, Mat& dst)
+{
+	Mat src = src_;
+	Mat out(src.cols, src.rows, src.type());
+	for (int i = 0; i < src.rows; ++i)
+		for (int j = 0; j < src.cols; ++j) out.ptr<float>(j)[i] = src.ptr<float>(i)[j];
+	dst = out;
+}
+
+// [assumed-OpenCV] GEMMSingleMul<float,double>: double accumulator over k ascending, cast to float
+inline Mat operator*(const Mat& a, const Mat& b)
+{
+	Mat c(a.rows, b.cols, CV_32F);
+	for (int i = 0; i < a.rows; ++i)
+		for (int j = 0; j < b.cols; ++j)
+		{
+			double s = 0;
+			for (int k = 0; k < a.cols; ++k) s += (double)a.ptr<float>(i)[k] * (double)b.ptr<float>(k)[j];
+			c.ptr<float>(i)[j] = (float)s;
+		}
+	return c;
+}
+
+namespace shim_detail {
+// [assumed-OpenCV] lapack.cpp JacobiSVDImpl_<float>: one-sided (Hestenes) Jacobi on the n rows (length m) of At.
+// On return the rows of At are the (normalised) left factors, W the singular values (descending), Vt the
+// accumulated rotations. hypot() is spelled sqrt(p*p+beta*beta) so that CPU and GPU restatements agree bit for bit.
+inline void jacobi_svd_f32(float* At, int astep, float* Wout, float* Vt, int vstep, int m, int n, int n1)
+{
+	const double minval = FLT_MIN;
+	const float eps = FLT_EPSILON * 2;
+	std::vector<double> W(n);
+	int max_iter = std::max(m, 30);
+	for (int i = 0; i < n; ++i)
+	{
+		double sd = 0;
+		for (int k = 0; k < m; ++k) { float t = At[i * astep + k]; sd += (double)t * t; }
+		W[i] = sd;
+		for (int k = 0; k < n; ++k) Vt[i * vstep + k] = 0;
+		Vt[i * vstep + i] = 1;
+	}
+	for (int iter = 0; iter < max_iter; ++iter)
+	{
+		bool changed = false;
+		for (int i = 0; i < n - 1; ++i)
+			for (int j = i + 1; j < n; ++j)
+			{
+				float* Ai = At + i * astep; float* Aj = At + j * astep;
+				double a = W[i], p = 0, b = W[j];
+				for (int k = 0; k < m; ++k) p += (double)Ai[k] * Aj[k];
+				if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
+				p *= 2;
+				double beta = a - b, gamma = std::sqrt(p * p + beta * beta);
+				float c, s;
+				if (beta < 0)
+				{
+					double delta = (gamma - beta) * 0.5;
+					s = (float)std::sqrt(delta / gamma);
+					c = (float)(p / (gamma * s * 2));
+				}
+				else
+				{
+					c = (float)std::sqrt((gamma + beta) / (gamma * 2));
+					s = (float)(p / (gamma * c * 2));
+				}
+				a = b = 0;
+				for (int k = 0; k < m; ++k)
+				{
+					float t0 = c * Ai[k] + s * Aj[k];
+					float t1 = -s * Ai[k] + c * Aj[k];
+					Ai[k] = t0; Aj[k] = t1;
+					a += (double)t0 * t0; b += (double)t1 * t1;
+				}
+				W[i] = a; W[j] = b;
+				changed = true;
+				float* Vi = Vt + i * vstep; float* Vj = Vt + j * vstep;
+				for (int k = 0; k < n; ++k)
+				{
+					float t0 = c * Vi[k] + s * Vj[k];
+					float t1 = -s * Vi[k] + c * Vj[k];
+					Vi[k] = t0; Vj[k] = t1;
+				}
+			}
+		if (!changed) break;
+	}
+	for (int i = 0; i < n; ++i)
+	{
+		double sd = 0;
+		for (int k = 0; k < m; ++k) { float t = At[i * astep + k]; sd += (double)t * t; }
+		W[i] = std::sqrt(sd);
+	}
+	for (int i = 0; i < n - 1; ++i)
+	{
+		int j = i;
+		for (int k = i + 1; k < n; ++k) if (W[j] < W[k]) j = k;
+		if (i != j)
+		{
+			std::swap(W[i], W[j]);
+			for (int k = 0; k < m; ++k) std::swap(At[i * astep + k], At[j * astep + k]);
+			for (int k = 0; k < n; ++k) std::swap(Vt[i * vstep + k], Vt[j * vstep + k]);
+		}
+	}
+	for (int i = 0; i < n; ++i) Wout[i] = (float)W[i];
+	for (int i = 0; i < n1; ++i)
+	{
+		double sd = i < n ? W[i] : 0;
+		// (OpenCV regenerates a random orthogonal vector for zero singular values; a rank-deficient colour
+		//  sample set never reaches the classifier with a usable matrix anyway -- left as zero here.)
+		float s = (float)(sd > minval ? 1 / sd : 0.);
+		for (int k = 0; k < m; ++k) At[i * astep + k] *= s;
+	}
+}
+}  // namespace shim_detail
+
+// [assumed-OpenCV] invert(src, dst, DECOMP_SVD) for CV_32F, any shape: SVD::compute + SVD::backSubst(identity)
+inline double invert(const Mat& src_, Mat& dst, int method)
+{
+	if (method != DECOMP_SVD || src_.depth() != CV_32F) { std::cerr << "cv-shim: invert: only DECOMP_SVD/CV_32F" << std::endl; std::abort(); }
+	Mat src = src_;
+	int m = src.rows, n = src.cols;
+	bool at = false;
+	if (m < n) { std::swap(m, n); at = true; }
+	// temp_a: n rows of length m (== src if at, else src^T)
+	std::vector<float> A((size_t)n * m), V((size_t)n * n), W(n);
+	for (int i = 0; i < n; ++i)
+		for (int k = 0; k < m; ++k) A[(size_t)i * m + k] = at ? src.ptr<float>(i)[k] : src.ptr<float>(k)[i];
+	shim_detail::jacobi_svd_f32(A.data(), m, W.data(), V.data(), n, m, n, n);
+	// at:  u = V^T (src.rows x nm), vt = A (nm x src.cols);  !at: u = A^T, vt = V
+	int M = src.rows, N = src.cols, nm = std::min(M, N);
+	auto U = [&](int r, int k) { return at ? V[(size_t)k * n + r] : A[(size_t)k * m + r]; };    // u(r,k), r<M
+	auto VT = [&](int k, int c) { return at ? A[(size_t)k * m + c] : V[(size_t)k * n + c]; };  // vt(k,c), c<N
+	// lapack.cpp SVBkSbImpl_ with b == identity: x (N x M) += v_k (x) (u_k / w_k), skipping w_k <= eps*sum(w)
+	Mat out(N, M, CV_32F);
+	for (int i = 0; i < N; ++i) for (int j = 0; j < M; ++j) out.ptr<float>(i)[j] = 0;
+	double threshold = 0;
+	for (int i = 0; i < nm; ++i) threshold += W[i];
+	threshold *= (double)(FLT_EPSILON * 2);
+	std::vector<double> buffer(M);
+	for (int k = 0; k < nm; ++k)
+	{
+		double wi = W[k];
+		if (std::abs(wi) <= threshold) continue;
+		wi = 1 / wi;
+		for (int j = 0; j < M; ++j) buffer[j] = U(j, k) * wi;
+		for (int i = 0; i < N; ++i)
+		{
+			float s = VT(k, i);
+			float* y = out.ptr<float>(i);
+			for (int j = 0; j < M; ++j) y[j] = (float)(y[j] + s * buffer[j]);
+		}
+	}
+	dst = out;
+	return W[0] >= FLT_EPSILON ? W[n - 1] / W[0] : 0;
+}
+
+}  // namespace cv

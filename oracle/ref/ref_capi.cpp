@@ -1,0 +1,276 @@
+// oracle/_ref/libcimbar_ref.so -- a flat C API around the REFERENCE's own classes, compiled from the sources
+// where they lie under /root/reference (see oracle/Makefile) against oracle/cvshim (OpenCV stand-in).
+//
+// TEST INFRASTRUCTURE ONLY: used to pin oracle/cimbar_oracle.c, to manufacture golden vectors / input frames,
+// and (optionally) as the "reference" CPU baseline in bench.py. Never linked or loaded by libcimbar_amd.
+//
+// Nothing here re-implements reference logic except the 6-line body of Decoder::decode_fountain
+// (src/lib/encoder/Decoder.h:171-189), repeated in RefDecoder::decode_fountain_masked so that the per-chunk
+// good/bad outcome (which aligned_stream only reports through its callback) can be observed.
+#include "cimb_translator/CimbDecoder.h"
+#include "cimb_translator/CimbReader.h"
+#include "cimb_translator/CimbWriter.h"
+#include "cimb_translator/Common.h"
+#include "cimb_translator/Config.h"
+#include "cimb_translator/Interleave.h"
+#include "encoder/Decoder.h"
+#include "encoder/Encoder.h"
+#include "encoder/ReedSolomon.h"
+#include "encoder/escrow_buffer_writer.h"
+#include "fountain/fountain_decoder_sink.h"
+#include "fountain/fountain_encoder_stream.h"
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <vector>
+
+namespace {
+
+// collects aligned_stream's good-chunk writes (same STREAM concept as fountain_decoder_sink / escrow_buffer_writer)
+struct chunk_collector
+{
+	unsigned _chunk;
+	std::vector<char> bytes;
+	long count = 0;
+	explicit chunk_collector(unsigned chunk) : _chunk(chunk) {}
+	bool good() const { return true; }
+	unsigned chunk_size() const { return _chunk; }
+	long tellp() const { return count; }
+	chunk_collector& write(const char* d, unsigned n) { bytes.insert(bytes.end(), d, d + n); count += n; return *this; }
+};
+
+struct TestableCimbDecoder : CimbDecoder
+{
+	using CimbDecoder::CimbDecoder;
+	void reset_ccm() { internal_ccm() = color_correction(); }
+	const std::vector<uint64_t>& hashes() const { return _tileHashes; }
+};
+
+struct ExposedReader : CimbReader
+{
+	using CimbReader::CimbReader;
+	const std::vector<char>& bitplane() const { return _grayscale.buffer(); }
+};
+
+struct RefDecoder : Decoder
+{
+	using Decoder::Decoder;
+
+	// Decoder::decode_fountain (Decoder.h:171-189) with the chunk outcome recorded beside update_metadata
+	unsigned decode_fountain_masked(const cv::Mat& img, chunk_collector& out, uint32_t& mask, bool pre, int cc)
+	{
+		CimbReader reader(img, _decoder, cimbar::Config::color_mode(), pre, cc);
+		unsigned chunk_size = cimbar::Config::fountain_chunk_size();
+		unsigned idx = 0;
+		mask = 0;
+		auto on_flush = [&](char* buf, size_t len) {
+			reader.update_metadata(buf, len, chunk_size);
+			if (buf != nullptr && len > 0) mask |= (1u << idx);
+			++idx;
+		};
+		aligned_stream<chunk_collector> aligner(out, out.chunk_size(), 0, on_flush);
+		return do_decode(reader, aligner);
+	}
+};
+
+void reset_thread_ccm()
+{
+	TestableCimbDecoder d(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), 0xFF);
+	d.reset_ccm();
+}
+
+std::shared_ptr<fountain_decoder_sink> g_sink;
+}
+
+extern "C" {
+
+int ref_configure(int mode_val)
+{
+	cimbar::Config::update(mode_val);
+	return 0;
+}
+
+// the 16 tile hashes as CimbDecoder computes them at construction (CimbDecoder.cpp:87-99)
+int ref_tile_hashes(uint64_t* out16)
+{
+	TestableCimbDecoder d(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), 0xFF);
+	for (unsigned i = 0; i < d.hashes().size() && i < 16; ++i) out16[i] = d.hashes()[i];
+	return (int)d.hashes().size();
+}
+
+// tile `color*16+symbol` rendered exactly as the encoder pastes it (CimbEncoder.cpp:20-25 -> Common.cpp:150-171); 8*8*3 bytes
+int ref_tile_rgb(unsigned symbol, unsigned color, unsigned color_mode, uint8_t* out192)
+{
+	cv::Mat t = cimbar::getTile(cimbar::Config::symbol_bits(), symbol, cimbar::Config::dark(), 1u << cimbar::Config::color_bits(), color, color_mode);
+	if (t.rows != 8 || t.cols != 8 || t.channels() != 3) return -1;
+	for (int y = 0; y < 8; ++y) std::memcpy(out192 + y * 24, t.ptr<uchar>(y), 24);
+	return 0;
+}
+
+// an empty frame: background + anchors + guides, no cells (CimbWriter.cpp:39-77)
+int ref_template_frame(uint8_t* out_rgb)
+{
+	CimbWriter w(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), cimbar::Config::color_mode());
+	cv::Mat img = w.image();
+	for (int y = 0; y < img.rows; ++y) std::memcpy(out_rgb + (size_t)y * img.cols * 3, img.ptr<uchar>(y), (size_t)img.cols * 3);
+	return img.rows * img.cols * 3;
+}
+
+// Encoder::encode_next (Encoder.h:69-129) over a raw byte stream: `n` payload bytes (<= 7500 per frame) -> one RGB frame
+int ref_encode_raw(const uint8_t* payload, unsigned n, uint8_t* out_rgb)
+{
+	std::stringstream ss(std::string((const char*)payload, n));
+	Encoder enc;
+	auto frame = enc.encode_next(ss);
+	if (!frame) return -1;
+	for (int y = 0; y < frame->rows; ++y) std::memcpy(out_rgb + (size_t)y * frame->cols * 3, frame->ptr<uchar>(y), (size_t)frame->cols * 3);
+	return frame->rows * frame->cols * 3;
+}
+
+// fountain-encode `data` (compression off) and render `nframes` consecutive frames (Encoder.h:167-190, :69-129;
+// EncoderPlus.h:45-98 minus the will_it_scan filter, which only matters when a Scanner is in front of the decoder)
+int ref_encode_fountain(const uint8_t* data, unsigned size, int encode_id, unsigned first_frame, unsigned nframes, uint8_t* out_rgb)
+{
+	std::stringstream ss(std::string((const char*)data, size));
+	Encoder enc;
+	enc.set_encode_id((uint8_t)encode_id);
+	fountain_encoder_stream::ptr fes = enc.create_fountain_encoder(ss, "", 0);
+	if (!fes) return -1;
+	size_t fsz = (size_t)cimbar::Config::image_size_x() * cimbar::Config::image_size_y() * 3;
+	for (unsigned f = 0; f < first_frame + nframes; ++f)
+	{
+		auto frame = enc.encode_next(*fes);
+		if (!frame) return (int)f;
+		if (f < first_frame) continue;
+		uint8_t* dst = out_rgb + (size_t)(f - first_frame) * fsz;
+		for (int y = 0; y < frame->rows; ++y) std::memcpy(dst + (size_t)y * frame->cols * 3, frame->ptr<uchar>(y), (size_t)frame->cols * 3);
+	}
+	return (int)nframes;
+}
+
+// the fountain chunk stream itself (what the frames above carry), 625 bytes per chunk
+int ref_fountain_chunks(const uint8_t* data, unsigned size, int encode_id, unsigned nchunks, uint8_t* out)
+{
+	std::stringstream ss(std::string((const char*)data, size));
+	Encoder enc;
+	enc.set_encode_id((uint8_t)encode_id);
+	fountain_encoder_stream::ptr fes = enc.create_fountain_encoder(ss, "", 0);
+	if (!fes) return -1;
+	unsigned cs = cimbar::Config::fountain_chunk_size();
+	for (unsigned c = 0; c < nchunks; ++c)
+	{
+		if (fes->readsome((char*)out + (size_t)c * cs, cs) != (std::streamsize)cs) return (int)c;
+	}
+	return (int)nchunks;
+}
+
+void ref_reset_ccm() { reset_thread_ccm(); }
+
+int ref_get_ccm(float* out9)
+{
+	TestableCimbDecoder d(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), 0xFF);
+	const color_correction& cc = d.get_ccm();
+	cv::Matx<float, 3, 3> m = cc.mat();
+	for (int i = 0; i < 9; ++i) out9[i] = m.val[i];
+	return cc.active() ? 1 : 0;
+}
+
+// Decoder::decode_fountain on one RGB8 frame. chunks: 12*625 bytes, slot j = fountain chunk j of the frame (zeros if dropped).
+// Returns the reference's return value (good bytes). reset_ccm!=0 clears the thread_local CCM first.
+int ref_decode_fountain(const uint8_t* rgb, unsigned w, unsigned h, int preprocess, int color_correction, int reset_ccm,
+                        uint8_t* chunks, uint32_t* good_mask)
+{
+	if (reset_ccm) reset_thread_ccm();
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	unsigned cs = cimbar::Config::fountain_chunk_size();
+	unsigned per_frame = cimbar::Config::fountain_chunks_per_frame(cimbar::Config::bits_per_cell());
+
+	RefDecoder dec;
+	chunk_collector col(cs);
+	uint32_t mask = 0;
+	unsigned res = dec.decode_fountain_masked(img, col, mask, preprocess != 0, color_correction);
+
+	std::memset(chunks, 0, (size_t)per_frame * cs);
+	size_t off = 0;
+	for (unsigned j = 0; j < per_frame; ++j)
+		if (mask & (1u << j))
+		{
+			std::memcpy(chunks + (size_t)j * cs, col.bytes.data() + off, cs);
+			off += cs;
+		}
+	if (good_mask) *good_mask = mask;
+	return (int)res;
+}
+
+// The literal public entry point, writing into an escrow_buffer_writer exactly like cimbard_scan_extract_decode
+// (cimbar_recv_js.cpp:160-188). Returns buffers_in_use()*625; chunks packed contiguously.
+int ref_decode_fountain_escrow(const uint8_t* rgb, unsigned w, unsigned h, int preprocess, int color_correction, int reset_ccm,
+                               uint8_t* bufspace)
+{
+	if (reset_ccm) reset_thread_ccm();
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	unsigned cs = cimbar::Config::fountain_chunk_size();
+	unsigned per_frame = cimbar::Config::fountain_chunks_per_frame(cimbar::Config::bits_per_cell());
+	escrow_buffer_writer ebw(bufspace, per_frame, cs);
+	Decoder dec;
+	dec.decode_fountain(img, ebw, preprocess != 0, color_correction);
+	return (int)(ebw.buffers_in_use() * cs);
+}
+
+// CimbReader internals for stage-level pinning: the packed bitplane (CimbReader.cpp:30-46), then the flood-ordered
+// symbol pass (CimbReader.cpp:139-162): per visit k -> cell index, drifted x, y, symbol bits.
+int ref_symbol_pass(const uint8_t* rgb, unsigned w, unsigned h, int preprocess, uint8_t* bitplane /* w*h/8 or NULL */,
+                    int32_t* visit /* 4 ints per cell or NULL */)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	TestableCimbDecoder d(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), 0xFF);
+	ExposedReader reader(img, d, cimbar::Config::color_mode(), preprocess != 0, 0);
+	if (bitplane) std::memcpy(bitplane, reader.bitplane().data(), std::min<size_t>(reader.bitplane().size(), (size_t)w * h / 8));
+	int k = 0;
+	while (!reader.done())
+	{
+		PositionData pos;
+		unsigned bits = reader.read(pos);
+		if (visit) { visit[4*k] = (int)pos.i; visit[4*k+1] = pos.x; visit[4*k+2] = pos.y; visit[4*k+3] = (int)bits; }
+		++k;
+	}
+	return k;
+}
+
+// colour classifier on explicit inputs (CimbDecoder.cpp:168-200), using the thread's current CCM
+int ref_best_color(float r, float g, float b)
+{
+	TestableCimbDecoder d(cimbar::Config::symbol_bits(), cimbar::Config::color_bits(), cimbar::Config::dark(), 0xFF);
+	return (int)d.get_best_color(r, g, b, cimbar::Config::color_mode());
+}
+
+// libcorrect through the reference's wrapper (ReedSolomon.h:23-47)
+int ref_rs_encode(const uint8_t* msg, unsigned msg_len, unsigned parity, uint8_t* out)
+{
+	ReedSolomon rs(parity);
+	return (int)rs.encode((const char*)msg, msg_len, (char*)out);
+}
+int ref_rs_decode(const uint8_t* enc, unsigned enc_len, unsigned parity, uint8_t* out)
+{
+	static thread_local std::unique_ptr<ReedSolomon> rs;
+	static thread_local unsigned rs_parity = 0;
+	if (!rs || rs_parity != parity) { rs.reset(new ReedSolomon(parity)); rs_parity = parity; }
+	return (int)rs->decode((const char*)enc, enc_len, (char*)out);
+}
+
+int ref_interleave_reverse(unsigned size, unsigned blocks, unsigned partitions, uint32_t* out)
+{
+	std::vector<unsigned> v = Interleave::interleave_reverse(size, blocks, partitions);
+	for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+	return (int)v.size();
+}
+
+// fountain_decoder_sink (fountain_decoder_sink.h:53-214) -- the rank-0 wirehair sink of BASELINE config 4
+int ref_sink_reset(unsigned chunk_size) { g_sink = std::make_shared<fountain_decoder_sink>(chunk_size); return 0; }
+int64_t ref_sink_decode_frame(const uint8_t* buf, unsigned size) { return g_sink ? g_sink->decode_frame((const char*)buf, size) : -100; }
+int ref_sink_is_done(uint32_t id) { return g_sink && g_sink->is_done(id) ? 1 : 0; }
+int ref_sink_recover(uint32_t id, uint8_t* out, unsigned size) { return g_sink && g_sink->recover(id, out, size) ? 1 : 0; }
+
+}  // extern "C"
