@@ -1,0 +1,67 @@
+/* oracle/cimbar_oracle.h -- CPU restatement of libcimbar's mode-B frame decode path.
+ *
+ * TEST INFRASTRUCTURE. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product (libcimbar_amd/) never links, imports or calls it.
+ *
+ * Parity status: PINNED against the reference's own code for this path, compiled from /root/reference by
+ * oracle/Makefile into oracle/_ref/libcimbar_ref.so (tests/test_oracle_vs_ref.py), and against the reference's
+ * known-answer vectors (tests/test_oracle_golden.py). The OpenCV primitives the reference calls (gray conversion,
+ * box-mean threshold, filter2D, SVD pseudo-inverse) are NOT in /root/reference; both this file and the cv-shim the
+ * reference is compiled against restate OpenCV 4.5.x's published arithmetic, so parity AT THE OPENCV BOUNDARY IS
+ * UNPINNED (see DESIGN.md "Oracle").
+ */
+#ifndef CIMBAR_ORACLE_H
+#define CIMBAR_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CO_IMG 1024
+#define CO_CELLS 12400
+#define CO_CHUNK 625
+#define CO_CHUNKS_PER_FRAME 12
+#define CO_RS_BLOCK 155
+#define CO_RS_PARITY 30
+#define CO_RS_DATA 125
+
+/* models the reference's `static thread_local color_correction` (CimbDecoder.cpp:69-73) */
+typedef struct co_ccm { float m[9]; int active; } co_ccm;
+
+void co_tile_hashes(uint64_t out16[16]);
+void co_cell_positions(int32_t* xy /* 2*CO_CELLS */);
+void co_interleave_reverse(uint32_t* out /* CO_CELLS */);
+void co_adjacent(int index, int32_t out4[4]);
+
+/* CimbReader.cpp:30-46 + bitmatrix.h:14-46: RGB8 -> packed bitplane (w*h/8 bytes, MSB = leftmost pixel) */
+void co_threshold_bitplane(const uint8_t* rgb, int w, int h, int preprocess, uint8_t* bitplane);
+
+/* CimbReader.cpp:139-162 + FloodDecodePositions.cpp + CimbDecoder.cpp:101-147: flood-ordered symbol pass.
+ * visit[4*k+0..3] = cell index, drifted x, drifted y, symbol of the k-th decoded cell. dist (optional): error distance.
+ * Returns the number of cells visited. */
+int co_symbol_pass(const uint8_t* bitplane, int32_t* visit, uint8_t* dist);
+
+/* libcorrect decode.c:299-379 (correct_reed_solomon_decode), GF(2^8) poly 0x187, fcr 1, gap 1 */
+int co_rs_decode(const uint8_t* enc, unsigned enc_len, unsigned parity, uint8_t* msg);
+/* libcorrect encode.c:3-34 */
+int co_rs_encode(const uint8_t* msg, unsigned msg_len, unsigned parity, uint8_t* enc);
+
+/* CimbDecoder.cpp:168-200 */
+unsigned co_best_color(float r, float g, float b, const co_ccm* ccm);
+
+/* Decoder::decode_fountain (Decoder.h:171-189) for one 1024x1024 RGB8 frame.
+ * chunks: 12*625 bytes, slot j = fountain chunk j (zero-filled if dropped); *good_mask bit j = chunk j delivered.
+ * ccm: in/out carried colour-correction state. Returns good bytes (625 * popcount(mask)). */
+int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
+                       uint8_t* chunks, uint32_t* good_mask);
+
+/* stage outputs of the last co_decode_fountain call on this thread (for stage-level parity tests) */
+const uint8_t* co_last_symbols(void);   /* CO_CELLS bytes, by cell index */
+const uint8_t* co_last_colors(void);    /* CO_CELLS bytes, by cell index */
+const int32_t* co_last_positions(void); /* 2*CO_CELLS, drifted x,y by cell index */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
