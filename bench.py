@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded cimbar frames/s (1024x1024 mode B) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+
+One "step" = one pass of the whole decode path (threshold -> symbols -> RS -> CCM -> colours -> RS -> chunks) over one
+device-resident batch of F synthetic clean mode-B frames (BASELINE.json configs[1]: F = 1024). For N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank decodes its own F frames (weak scaling) and the step ends with the
+gather of the decoded chunks to rank 0 over RCCL. Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline      dominant kernel's ALGORITHMIC bytes/s (3 153 232 B per frame) vs 8 TB/s HBM, timed live
+                with HIP events on the launch stream inside the library
+  cpu_baseline  the CPU decoder timed on this host on a bounded sample of the same frames ("reference" = the
+                reference's own sources built into oracle/_ref, else "port" = oracle/cimbar_oracle.c)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from libcimbar_amd import HipDecoder, framegen, modeb, multigpu  # noqa: E402
+
+ALGO_BYTES_PER_FRAME = modeb.FRAME_RGB_BYTES + modeb.FRAME_BYTES + 4   # 3 153 232, SURVEY.md 8(d)
+HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_frames(n, device, seed):
+    synth = framegen.FrameSynth(device)
+    payload = framegen.synth_payload(n, seed=seed, device=device)
+    frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=device)
+    step = 64
+    for lo in range(0, n, step):
+        synth.frames_from_payload(payload[lo:lo + step], out=frames[lo:lo + step])
+    return payload, frames
+
+
+def cpu_baseline(frames_host, budget_s=15.0):
+    """Time the CPU decoder on host cores over a bounded sample of the same frames."""
+    from oracle import pyref
+    import ctypes
+    ref = pyref.ref_lib()
+    kind = "reference" if ref is not None else "port"
+    orc = pyref.oracle_lib()
+    ncores = os.cpu_count() or 1
+    threads = max(1, min(ncores, 32, len(frames_host)))
+
+    def decode_one(fr, state):
+        if ref is not None:
+            chunks = np.zeros(7500, np.uint8)
+            mask = ctypes.c_uint32(0)
+            return ref.ref_decode_fountain(pyref.P(fr), 1024, 1024, 0, 2, 0, pyref.P(chunks), ctypes.byref(mask))
+        chunks = np.zeros(7500, np.uint8)
+        mask = ctypes.c_uint32(0)
+        return orc.co_decode_fountain(pyref.P(fr), 1024, 1024, 0, 2, ctypes.byref(state), pyref.P(chunks), ctypes.byref(mask))
+
+    # single-thread probe sizes the sample
+    st = pyref.CoCcm()
+    t0 = time.perf_counter()
+    decode_one(frames_host[0], st)
+    decode_one(frames_host[0], st)
+    per_frame = (time.perf_counter() - t0) / 2
+    total = int(max(threads, min(len(frames_host), budget_s / per_frame * threads)))
+    done = [0] * threads
+
+    def worker(tid):
+        state = pyref.CoCcm()
+        for k in range(tid, total, threads):
+            if decode_one(frames_host[k % len(frames_host)], state) != 7500:
+                raise RuntimeError("cpu baseline decoded a clean frame incorrectly")
+            done[tid] += 1
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": threads, "kind": kind,
+            "sample": f"{sum(done)} clean mode-B 1024x1024 frames from the bench batch, {threads} threads x 1 decoder each, "
+                      f"{dt:.1f} s wall, single-thread {1.0 / per_frame:.1f} frames/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (BASELINE configs[1]: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.frames
+    payload, frames = make_frames(n, dev, seed=1234 + rank)
+    chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+    dec = HipDecoder(local_rank)
+    dec.enable_timing(True)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
+        if world > 1:
+            return multigpu.gather_chunks(chunks, masks, dst=0)
+        return chunks, masks
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_chunks, all_masks = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered
+    ok = bool((masks == 0xFFF).all().item()) and bool((chunks == payload).all().item())
+    if world > 1 and rank == 0:
+        ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item())
+    if not ok:
+        raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
+
+    # per-kernel times of one more (profiled) step: HIP events on the launch stream, recorded inside the library
+    reps = 5
+    for _ in range(reps):
+        dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        for k, v in dec.stage_times().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v / reps
+
+    if rank == 0:
+        frames_per_s = world * n * args.steps / elapsed
+        dom = max(stage_acc, key=stage_acc.get)
+        dom_ms = stage_acc[dom]
+        achieved = ALGO_BYTES_PER_FRAME * n / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "decoded cimbar frames/s (1024x1024 mode-B)", "value": round(frames_per_s, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"batch of {n} synthetic clean mode-B frames per GPU, device-resident, bit-exact vs encoded payload",
+                       "frames_per_gpu_per_step": n, "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "whole_path_frac": round(frames_per_s / world * ALGO_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = frames[:min(n, 64)].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+/* cimbar_hip.h -- C ABI of the MI355X (gfx950) cimbar mode-B frame-decode path.
+ *
+ * Drop-in boundary: everything between "a deskewed 1024x1024 RGB8 frame" and "the <=12 fountain chunks of 625 bytes
+ * that libcimbar hands to fountain_decoder_sink::write". It replaces, for that path only, what the reference does in
+ *     Decoder::decode_fountain            /root/reference/src/lib/encoder/Decoder.h:171-189 (-> do_decode :60-118)
+ *     CimbReader / CimbDecoder            src/lib/cimb_translator/CimbReader.cpp:107-280, CimbDecoder.cpp:101-217
+ *     reed_solomon_stream / aligned_stream src/lib/encoder/reed_solomon_stream.h:54-77, aligned_stream.h:39-119
+ * and mirrors the shape of the reference's own C ABI for the same step,
+ *     cimbard_get_bufsize / cimbard_scan_extract_decode / cimbard_configure_decode
+ *                                          src/lib/cimbar_js/cimbar_recv_js.h:16-17,36; cimbar_recv_js.cpp:143-189
+ * (minus the Scanner/Extractor call, which is upstream of this path).
+ *
+ * Conventions: plain C types, caller-allocated buffers, no exceptions across the boundary. Functions returning int
+ * return >= 0 on success and a negative CIMBAR_HIP_E* code on failure. One context serves one host thread at a time
+ * and carries the colour-correction matrix from frame to frame exactly like the reference's `static thread_local`
+ * CCM (CimbDecoder.cpp:69-73). There is NO CPU fallback: if no gfx950 device/kernel image is usable, create() fails.
+ */
+#ifndef CIMBAR_HIP_H
+#define CIMBAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIMBAR_HIP_FRAME_DIM 1024          /* Conf8x8 image_size_x/y, GridConf.h:130-131 */
+#define CIMBAR_HIP_CELLS 12400             /* GridConf.h:42-45 */
+#define CIMBAR_HIP_CHUNK_SIZE 625          /* Config::fountain_chunk_size(), GridConf.h:63-71 */
+#define CIMBAR_HIP_CHUNKS_PER_FRAME 12     /* Config::fountain_chunks_per_frame(6), GridConf.h:54-61 */
+#define CIMBAR_HIP_FRAME_BYTES (CIMBAR_HIP_CHUNK_SIZE * CIMBAR_HIP_CHUNKS_PER_FRAME) /* 7500 = cimbard_get_bufsize() */
+
+enum {
+	CIMBAR_HIP_OK = 0,
+	CIMBAR_HIP_EINVAL = -1,       /* bad argument (null pointer, n <= 0, unsupported mode) */
+	CIMBAR_HIP_EDIM = -2,         /* frame is not 1024x1024 RGB8 (cf. CimbReader::_good, CimbReader.cpp:119) */
+	CIMBAR_HIP_ENODEVICE = -3,    /* no usable gfx950 device / kernel image */
+	CIMBAR_HIP_EHIP = -4,         /* a HIP runtime call failed; see cimbar_hip_last_error() */
+	CIMBAR_HIP_ENOMEM = -5
+};
+
+/* where a buffer argument lives */
+enum { CIMBAR_HIP_MEM_HOST = 0, CIMBAR_HIP_MEM_DEVICE = 1 };
+
+typedef struct cimbar_hip_ctx cimbar_hip_ctx;
+
+/* cimbard_configure_decode(mode) + `Decoder dec;` : only mode 68 ("B", Conf8x8) is implemented; 0 selects it too
+ * (Config::temp_conf default, Config.h:19-44). `device` is a HIP device ordinal. */
+int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out);
+void cimbar_hip_destroy(cimbar_hip_ctx* ctx);
+
+/* cimbard_get_bufsize(): bytes of chunk space one frame needs (12 * 625) */
+int cimbar_hip_bufsize(void);
+
+/* human-readable text of the last failure on this context (never NULL) */
+const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
+
+/* Decoder::decode_fountain(img, sink, should_preprocess, color_correction) for ONE host-resident frame.
+ *   rgb        : height rows of `stride` bytes, width*3 used (RGB8, as cv::Mat CV_8UC3 after BGR2RGB, cimbar.cpp:132-133)
+ *   chunks     : 12*625 bytes; slot j holds fountain chunk j of the frame, zero-filled if the chunk was dropped
+ *   good_mask  : bit j set <=> aligned_stream delivered chunk j to the sink (aligned_stream.h:62-85)
+ * Returns the reference's return value: cumulative good bytes = 625 * popcount(mask) (Decoder.h:116-117). */
+int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
+                            int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask);
+
+/* The same for `n` independent frames, decoded in frame order (frame f's CCM carry-over sees frames < f).
+ *   rgb        : n densely packed 1024*1024*3 frames, in host or device memory (rgb_mem)
+ *   chunks     : n*7500 bytes, masks: n words, in host or device memory (out_mem)
+ *   hip_stream : a hipStream_t to enqueue on (NULL = the context's own stream). With device outputs the call only
+ *                enqueues work and returns 0; the caller synchronises the stream. With host outputs it synchronises
+ *                and returns the total good bytes over the batch (may exceed INT_MAX only beyond 286k frames).
+ */
+int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
+                                int color_correction, uint8_t* chunks, uint32_t* masks, int out_mem, void* hip_stream);
+
+/* Clears the carried colour-correction state (what a fresh thread starts with in the reference). */
+int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx);
+/* Current carried CCM, row-major 3x3; returns 1 if active, 0 if not (CimbDecoder::get_ccm, CimbDecoder.cpp:76-80). */
+int cimbar_hip_get_ccm(cimbar_hip_ctx* ctx, float out9[9]);
+
+/* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
+enum {
+	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */
+	CIMBAR_HIP_TAP_SYMBOLS = 1,    /* n * 12400 bytes : symbol (0..15) by linear cell index */
+	CIMBAR_HIP_TAP_COLORS = 2,     /* n * 12400 bytes : colour (0..3) by linear cell index */
+	CIMBAR_HIP_TAP_DRIFT = 3,      /* n * 12400 * 2 int8: accumulated (dx,dy) at which each cell's colour is read */
+	CIMBAR_HIP_TAP_RS_OK = 4,      /* n * 60 bytes    : 1 = libcorrect-equivalent decode returned > 0, per RS block */
+	CIMBAR_HIP_TAP_FLOOD = 5,      /* n bytes         : 1 = frame needed the exact flood-order pass */
+	CIMBAR_HIP_TAP_CCM = 6         /* n * 10 floats   : 3x3 matrix used for the colour pass + active flag */
+};
+int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes);
+
+/* Average device time (ms) of each pipeline stage over the last decode_batch call that ran with timing enabled
+ * (HIP events on the launch stream). names: static strings. Returns the number of stages written (<= max). */
+int cimbar_hip_enable_timing(cimbar_hip_ctx* ctx, int on);
+int cimbar_hip_stage_times(cimbar_hip_ctx* ctx, const char** names, float* ms, int max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIMBAR_HIP_H */

@@ -1,0 +1,1430 @@
+// cimbar_hip.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for libcimbar's mode-B frame-decode path.
+//
+// One deskewed 1024x1024 RGB8 frame -> <=12 fountain chunks of 625 bytes, bit-exact with the reference's
+// Decoder::decode_fountain (src/lib/encoder/Decoder.h:171-189). See include/cimbar_hip.h for the boundary and
+// DESIGN.md for the data layout / roofline notes. Paths in comments are relative to /root/reference/src.
+//
+// Pipeline (all on one HIP stream, a batch of F frames per launch; nothing here is GEMM-shaped, so no MFMA):
+//   K1 k_threshold      RGB -> gray -> (sharpen) -> 5x5|7x7 box-mean threshold -> bitplane   [HBM-read bound]
+//   K2 k_symbols        every cell at drift (0,0): 10x10 bit window -> 5|9 shifted 8x8 hashes -> popcount match;
+//                       flags the frame if any cell prefers a shifted window (order then matters -> K2b)
+//   K2b k_flood         exact emulation of the reference's priority-flood order + drift, one wavefront per flagged frame
+//   K3 k_rs             de-interleave + RS(155,125) decode, one block per wavefront (symbols: 40 blocks)
+//   K4 k_frame_mid      aligned_stream bookkeeping for the symbol chunks, fountain-header prediction, CCM derivation
+//   K5 k_colors         6x6 cell mean -> CCM -> palette classifier
+//   K3 k_rs             (colours: 20 blocks)
+//   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cimbar_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ mode-B constants
+// lib/cimb_translator/GridConf.h:121-142 (Conf8x8); Config.h:101-165
+constexpr int IMG = 1024;
+constexpr int PITCH = 9, OFFSET = 8, DIM = 112, MARKER = 6;
+constexpr int TOP_W = DIM - 2 * MARKER;               // 100
+constexpr int TOP_CELLS = TOP_W * MARKER;             // 600
+constexpr int MID_CELLS = DIM * (DIM - 2 * MARKER);   // 11200
+constexpr int NCELLS = 12400;
+constexpr int RS_BLOCK = 155, RS_PARITY = 30, RS_DATA = 125;
+constexpr int SYM_BLOCKS = 40, COL_BLOCKS = 20, ALL_BLOCKS = 60;
+constexpr int CHUNK = 625, CHUNKS = 12, FRAME_BYTES = CHUNK * CHUNKS;
+constexpr int PLANE_WORDS = IMG * IMG / 32;           // 32768 u32 per frame
+constexpr size_t FRAME_RGB = (size_t)IMG * IMG * 3;
+constexpr int ANCHOR = 30;
+constexpr int HEAP_CAP = 12 * NCELLS + 64;            // <= 12 offers per decoded cell + 8 seeds
+
+// the 16 tile hashes (CimbDecoder.cpp:87-99 computes them from bitmaps.h; checked against the reference build in tests)
+__constant__ uint64_t c_tile[16] = {
+	0xfffefcf8f0e0c080ULL, 0x80c0e0f0f8fcfeffULL, 0xff7f3f1f0f070301ULL, 0x0103070f1f3f7fffULL,
+	0x181818ffff181818ULL, 0x66e7e70000e7e766ULL, 0x3c7ee7c3c3e77e3cULL, 0x18183c3c7e7effffULL,
+	0xc0f0fcfffffcf0c0ULL, 0xfffcf00000f0fcffULL, 0xff3f0f00000f3fffULL, 0xe7e7e7e7c3c38181ULL,
+	0x8181c3c3e7e7e7e7ULL, 0x0000c3e77e3c1800ULL, 0x0c1c387070381c0cULL, 0x1e1e38381c1c7878ULL};
+
+// Common.cpp:21-31 getColor4 (colour_mode 1)
+__constant__ int c_palette[4][3] = {{0, 255, 0}, {0, 255, 255}, {255, 255, 0}, {255, 0, 255}};
+
+// GF(2^8), primitive poly 0x187 (libcorrect field.h:26-62): exp[512], log[256]
+__constant__ uint8_t c_gf_exp[512];
+__constant__ uint8_t c_gf_log[256];
+
+struct Tables {
+	ushort2* cell_xy;        // [NCELLS] top-left pixel of each cell (CellPositions.cpp:5-51)
+	uint16_t* stream_cell;   // [NCELLS] stream index -> linear cell index (Interleave.h:8-24)
+	int16_t* adj;            // [NCELLS][4] right, left, bottom, top (AdjacentCellFinder.cpp:16-105)
+};
+
+// ------------------------------------------------------------------------------------------------ K1 threshold+pack
+// CimbReader.cpp:30-46 preprocessSymbolGrid + bitmatrix.h:14-46. One wavefront owns a full-width strip of ROWS pixel
+// rows: lane l holds columns [16l, 16l+16) and the wave walks down the strip, so every RGB byte is loaded once
+// (3 x 16 B per lane per row), the 5x5|7x7 box sums live in registers and no LDS / barrier is needed.
+//   gray  = (R*9798 + G*19235 + B*3735 + 2^14) >> 15                                 [assumed-OpenCV]
+//   bit   = gray > round(box_sum / n)   <=>   n*gray > box_sum + n/2   (n = 25 | 49), BORDER_REPLICATE
+// Output layout: plane[frame][row][32 words], pixel x -> word x/32, bit 31-(x%32).
+constexpr int K1_ROWS = 32;
+
+__device__ __forceinline__ void load_row48(const uint8_t* __restrict__ row, int lane, uint32_t d[12])
+{
+	const uint4* p = reinterpret_cast<const uint4*>(row + lane * 48);
+	uint4 a = p[0], b = p[1], c = p[2];
+	d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+	d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+	d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w;
+}
+
+__device__ __forceinline__ uint32_t byte_of(const uint32_t d[12], int k) { return (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; }
+
+// 16 gray pixels of this lane, g[p]
+__device__ __forceinline__ void gray16(const uint32_t d[12], uint32_t g[16])
+{
+#pragma unroll
+	for (int p = 0; p < 16; ++p)
+		g[p] = (byte_of(d, 3 * p) * 9798u + byte_of(d, 3 * p + 1) * 19235u + byte_of(d, 3 * p + 2) * 3735u + 16384u) >> 15;
+}
+
+// neighbours' edge pixels: lo = pixels [-RAD..-1] (from lane-1), hi = pixels [16..16+RAD-1] (from lane+1), with the
+// image border handled by the caller-supplied policy (replicate for the box filter, reflect101 for the sharpen taps)
+template <int RAD>
+__device__ __forceinline__ void halo(const uint32_t g[16], int lane, bool reflect, uint32_t ext[16 + 2 * RAD])
+{
+	uint32_t tail = 0, head = 0;
+#pragma unroll
+	for (int k = 0; k < RAD; ++k) { tail |= g[16 - RAD + k] << (8 * k); head |= g[k] << (8 * k); }
+	uint32_t from_left = __shfl_up(tail, 1), from_right = __shfl_down(head, 1);
+#pragma unroll
+	for (int p = 0; p < 16; ++p) ext[RAD + p] = g[p];
+#pragma unroll
+	for (int k = 0; k < RAD; ++k) {
+		uint32_t l = (from_left >> (8 * k)) & 0xFFu;      // pixel (-RAD + k)
+		uint32_t r = (from_right >> (8 * k)) & 0xFFu;     // pixel (16 + k)
+		if (lane == 0) l = reflect ? g[RAD - k] : g[0];
+		if (lane == 63) r = reflect ? g[14 - k] : g[15];
+		ext[k] = l;
+		ext[16 + RAD + k] = r;
+	}
+}
+
+// horizontal (2*RAD+1)-sums of the 16 pixels, packed two u16 per register: out[q] = h[2q] | h[2q+1] << 16
+template <int RAD>
+__device__ __forceinline__ void hsum16(const uint32_t ext[16 + 2 * RAD], uint32_t out[8])
+{
+	uint32_t s = 0;
+#pragma unroll
+	for (int k = 0; k < 2 * RAD + 1; ++k) s += ext[k];
+	uint32_t h[16];
+	h[0] = s;
+#pragma unroll
+	for (int p = 1; p < 16; ++p) { s += ext[p + 2 * RAD] - ext[p - 1]; h[p] = s; }
+#pragma unroll
+	for (int q = 0; q < 8; ++q) out[q] = h[2 * q] | (h[2 * q + 1] << 16);
+}
+
+__device__ __forceinline__ void pack_gray(const uint32_t g[16], uint32_t out[4])
+{
+#pragma unroll
+	for (int q = 0; q < 4; ++q) out[q] = g[4 * q] | (g[4 * q + 1] << 8) | (g[4 * q + 2] << 16) | (g[4 * q + 3] << 24);
+}
+
+// gray row `r` (already clamped/reflected by the caller) for this lane
+__device__ __forceinline__ void gray_row(const uint8_t* __restrict__ frame, int r, int lane, uint32_t g[16])
+{
+	uint32_t d[12];
+	load_row48(frame + (size_t)r * (IMG * 3), lane, d);
+	gray16(d, g);
+}
+
+// CimbReader.cpp:17-27 sharpen: filter2D with [0 -1 0; -1 4.5 -1; 0 -1 0], BORDER_REFLECT_101, saturate(round-half-even)
+__device__ __forceinline__ void sharp_row(const uint8_t* __restrict__ frame, int r, int lane, uint32_t s[16])
+{
+	uint32_t gn[16], gc[16], gs[16];
+	int rn = r - 1 < 0 ? 1 : r - 1, rs = r + 1 >= IMG ? IMG - 2 : r + 1;
+	gray_row(frame, rn, lane, gn);
+	gray_row(frame, r, lane, gc);
+	gray_row(frame, rs, lane, gs);
+	uint32_t ext[18];
+	halo<1>(gc, lane, true, ext);
+#pragma unroll
+	for (int p = 0; p < 16; ++p) {
+		int t = 9 * (int)gc[p] - 2 * (int)(gn[p] + gs[p] + ext[p] + ext[p + 2]);   // = 2 * (4.5c - n - s - w - e), exact
+		int q = t >> 1;
+		if (t & 1) q += (q & 1);                                                   // x.5 -> nearest even
+		s[p] = (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+	}
+}
+
+template <int RAD, bool PRE>
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane)
+{
+	constexpr int N = (2 * RAD + 1) * (2 * RAD + 1);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int strip = blockIdx.x * 4 + wave;
+	const int f = blockIdx.y;
+	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
+	uint32_t* out = plane + (size_t)f * PLANE_WORDS;
+	const int y0 = strip * K1_ROWS;
+
+	uint32_t hring[2 * RAD + 1][8];   // horizontal sums of the last 2*RAD+1 rows (packed u16 pairs)
+	uint32_t gring[RAD + 1][4];       // gray of the last RAD+1 rows (packed bytes); [0] is the row being emitted
+	uint32_t V[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) V[q] = 0;
+#pragma unroll
+	for (int k = 0; k < 2 * RAD + 1; ++k)
+#pragma unroll
+		for (int q = 0; q < 8; ++q) hring[k][q] = 0;
+#pragma unroll
+	for (int k = 0; k < RAD + 1; ++k)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) gring[k][q] = 0;
+
+	for (int t = 0; t < K1_ROWS + 2 * RAD; ++t) {
+		int y = y0 - RAD + t;
+		int yc = y < 0 ? 0 : (y >= IMG ? IMG - 1 : y);          // BORDER_REPLICATE on the thresholded image's source
+		uint32_t g[16];
+		if (PRE) sharp_row(frame, yc, lane, g);
+		else gray_row(frame, yc, lane, g);
+
+		uint32_t ext[16 + 2 * RAD];
+		halo<RAD>(g, lane, false, ext);
+		// shift the rings, append the new row
+#pragma unroll
+		for (int k = 0; k < 2 * RAD; ++k)
+#pragma unroll
+			for (int q = 0; q < 8; ++q) hring[k][q] = hring[k + 1][q];
+		hsum16<RAD>(ext, hring[2 * RAD]);
+#pragma unroll
+		for (int k = 0; k < RAD; ++k)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) gring[k][q] = gring[k + 1][q];
+		pack_gray(g, gring[RAD]);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) V[q] += hring[2 * RAD][q];
+
+		if (t >= 2 * RAD) {
+			// emit row y - RAD: its gray is gring[0], its box sum is V
+			uint32_t bits = 0;
+#pragma unroll
+			for (int p = 0; p < 16; ++p) {
+				uint32_t gp = (gring[0][p >> 2] >> (8 * (p & 3))) & 0xFFu;
+				uint32_t vp = (V[p >> 1] >> (16 * (p & 1))) & 0xFFFFu;
+				bits |= (uint32_t)(gp * (uint32_t)N > vp + (uint32_t)(N / 2)) << (15 - p);
+			}
+			uint16_t* row16 = reinterpret_cast<uint16_t*>(out + (size_t)(y - RAD) * 32);
+			row16[lane ^ 1] = (uint16_t)bits;   // even lane = high half of word lane/2 (little-endian halves)
+#pragma unroll
+			for (int q = 0; q < 8; ++q) V[q] -= hring[0][q];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ symbol matching
+// 10x10 bit window whose top-left pixel is (x0, y0): ten 10-bit rows, MSB = leftmost (average_hash.h:63-75)
+__device__ __forceinline__ void window_rows(const uint32_t* __restrict__ plane, int x0, int y0, uint32_t rows[10])
+{
+	const int j = x0 >> 5, sh = 54 - (x0 & 31);
+	const int j1 = j + 1 > 31 ? 31 : j + 1;   // when j == 31 the window ends inside word 31 (x0 <= 1013)
+#pragma unroll
+	for (int i = 0; i < 10; ++i) {
+		const uint32_t* r = plane + (size_t)(y0 + i) * 32;
+		uint64_t v = ((uint64_t)r[j] << 32) | r[j1];
+		rows[i] = (uint32_t)(v >> sh) & 0x3FFu;
+	}
+}
+
+// ahash_result.h:70-106 / bit_extractor.h:23-51: window id w = 8x8 block at column w%3, row w/3 of the 10x10 window
+__device__ __forceinline__ uint64_t window_hash(const uint32_t rows[10], int w)
+{
+	const int cs = 2 - (w % 3), r0 = w / 3;
+	uint64_t h = 0;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) h = (h << 8) | ((rows[r0 + k] >> cs) & 0xFFu);
+	return h;
+}
+
+// best (distance << 4 | tile) over the 16 tiles for one hash; first minimum wins (CimbDecoder.cpp:111-131)
+__device__ __forceinline__ uint32_t best_tile(uint64_t h)
+{
+	uint32_t best = 0xFFFFu;
+#pragma unroll
+	for (int t = 0; t < 16; ++t) {
+		uint32_t d = (uint32_t)__popcll(h ^ c_tile[t]);
+		uint32_t key = (d << 4) | (uint32_t)t;
+		best = key < best ? key : best;
+	}
+	return best;
+}
+
+__device__ __forceinline__ bool is_seed(int i)
+{
+	// FloodDecodePositions.cpp:27-41
+	return i == 0 || i == TOP_W - 1 || i == NCELLS - 1 || i == NCELLS - TOP_W || i == TOP_CELLS || i == TOP_CELLS + DIM - 1 ||
+	       i == NCELLS - 1 - TOP_CELLS || i == NCELLS - TOP_CELLS - DIM;
+}
+
+// K2: every cell evaluated at drift (0,0). If, for every cell, no shifted window beats the centre one (4 side windows
+// for ordinary cells, all 8 for the flood seeds, which may be popped in 9-window mode), the reference's flood visits
+// every cell at drift (0,0) with cooldown 4|0xFE whatever its heap order, so symbol = argmin_tile popcnt(centre ^ tile)
+// exactly (DESIGN.md "fast path"). Otherwise flag the frame for K2b.
+__global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ plane, Tables tb, uint8_t* __restrict__ symbols,
+                                                 uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int f = blockIdx.y;
+	if (i >= NCELLS) return;
+	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
+	ushort2 xy = tb.cell_xy[i];
+	uint32_t rows[10];
+	window_rows(pl, (int)xy.x - 1, (int)xy.y - 1, rows);
+
+	uint32_t centre = best_tile(window_hash(rows, 4));
+	uint32_t dc = centre >> 4;
+	bool shifted = false;
+	if (dc != 0) {
+		uint32_t other = 0xFFFFu;
+		const int side[4] = {5, 7, 3, 1};
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { uint32_t b = best_tile(window_hash(rows, side[k])); other = b < other ? b : other; }
+		if (is_seed(i)) {
+			const int corner[4] = {8, 0, 2, 6};
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { uint32_t b = best_tile(window_hash(rows, corner[k])); other = b < other ? b : other; }
+		}
+		shifted = (other >> 4) < dc;
+	}
+	symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
+	if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
+	if (__any(shifted)) {
+		if ((threadIdx.x & 63) == 0) atomicOr(&flood_flag[f], 1u);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K2b exact flood
+// FloodDecodePositions.cpp:17-134 + CimbReader.cpp:139-162 + CimbDecoder.cpp:101-147, literally, one wavefront per
+// flagged frame. The priority queue replays libstdc++'s push_heap/pop_heap (bits/stl_heap.h) so that equal-priority
+// cells pop in the same order as std::priority_queue; lane 0 owns the heap, all 64 lanes share the popcount work.
+struct FloodScratch {
+	uint32_t* heap;      // [F][HEAP_CAP]  (prio << 16) | idx ; ordering compares prio only
+	uint32_t* instr;     // [F][NCELLS]    dx+8 | (dy+8) << 8 | prio << 16 | cooldown << 24
+	uint8_t* remaining;  // [F][NCELLS]
+};
+
+__device__ __forceinline__ void heap_sift_up(uint32_t* h, int hole, int top, uint32_t value)
+{
+	int parent = (hole - 1) / 2;
+	while (hole > top && (h[parent] >> 16) > (value >> 16)) {
+		h[hole] = h[parent];
+		hole = parent;
+		parent = (hole - 1) / 2;
+	}
+	h[hole] = value;
+}
+__device__ __forceinline__ void heap_push(uint32_t* h, int& n, uint32_t e)
+{
+	h[n] = e;
+	++n;
+	heap_sift_up(h, n - 1, 0, e);
+}
+__device__ __forceinline__ uint32_t heap_pop(uint32_t* h, int& n)
+{
+	uint32_t top = h[0];
+	if (n > 1) {
+		int len = n - 1;
+		uint32_t value = h[len];
+		h[len] = top;
+		int hole = 0, second = 0;
+		while (second < (len - 1) / 2) {
+			second = 2 * (second + 1);
+			if ((h[second] >> 16) > (h[second - 1] >> 16)) second--;
+			h[hole] = h[second];
+			hole = second;
+		}
+		if ((len & 1) == 0 && second == (len - 2) / 2) {
+			second = 2 * (second + 1);
+			h[hole] = h[second - 1];
+			hole = second - 1;
+		}
+		heap_sift_up(h, hole, 0, value);
+	}
+	--n;
+	return top;
+}
+
+__device__ __forceinline__ uint32_t calc_cooldown(uint32_t previous, uint32_t idx)
+{
+	// CellDrift.cpp:33-43
+	if (idx == 4) return 4;
+	if ((idx & 1) == 0) return 0xFF;
+	if (((previous ^ idx) & 0xFF) == 6) return 0xFF;
+	return idx;
+}
+
+__device__ __forceinline__ void offer(int next, uint32_t* h, int& hn, uint32_t* instr, const uint8_t* remaining, int dx, int dy,
+                                      uint32_t dist, uint32_t cooldown)
+{
+	// FloodDecodePositions.cpp:69-83 update_adjacents, one neighbour
+	if (next < 0 || !remaining[next]) return;
+	uint32_t di = instr[next];
+	if (((di >> 16) & 0xFF) <= dist) return;
+	instr[next] = (uint32_t)(dx + 8) | ((uint32_t)(dy + 8) << 8) | ((dist & 0xFF) << 16) | (cooldown << 24);
+	heap_push(h, hn, ((dist & 0xFF) << 16) | (uint32_t)next);
+}
+
+__global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane, Tables tb, FloodScratch sc,
+                                              const uint32_t* __restrict__ flood_flag, uint8_t* __restrict__ symbols,
+                                              int8_t* __restrict__ drift, uint8_t* __restrict__ dist_out)
+{
+	const int f = blockIdx.x, lane = threadIdx.x;
+	if (!flood_flag[f]) return;
+	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
+	uint32_t* h = sc.heap + (size_t)f * HEAP_CAP;
+	uint32_t* instr = sc.instr + (size_t)f * NCELLS;
+	uint8_t* remaining = sc.remaining + (size_t)f * NCELLS;
+
+	for (int i = lane; i < NCELLS; i += 64) { instr[i] = 8u | (8u << 8) | (0xFEu << 16) | (0xFEu << 24); remaining[i] = 1; }
+	__syncthreads();
+
+	__shared__ int s_cell;
+	__shared__ int s_hn;
+	if (lane == 0) {
+		int hn = 0;
+		const uint32_t last = NCELLS - 1;
+		heap_push(h, hn, 0u);
+		heap_push(h, hn, (uint32_t)(TOP_W - 1));
+		heap_push(h, hn, last);
+		heap_push(h, hn, last - (TOP_W - 1));
+		heap_push(h, hn, (1u << 16) | (uint32_t)TOP_CELLS);
+		heap_push(h, hn, (1u << 16) | (uint32_t)(TOP_CELLS + DIM - 1));
+		heap_push(h, hn, (1u << 16) | (last - TOP_CELLS));
+		heap_push(h, hn, (1u << 16) | (last - (TOP_CELLS + DIM - 1)));
+		s_hn = hn;
+	}
+	__syncthreads();
+
+	const int ORDER[9] = {4, 5, 7, 3, 1, 8, 0, 2, 6};   // ahash_result.h:26
+	for (int count = 0; count < NCELLS; ++count) {
+		if (lane == 0) {
+			int hn = s_hn, cell = -1;
+			while (hn > 0) {                                   // FloodDecodePositions.cpp:49-67 next()
+				uint32_t e = heap_pop(h, hn);
+				int idx = (int)(e & 0xFFFFu);
+				if (!remaining[idx]) continue;
+				remaining[idx] = 0;
+				cell = idx;
+				break;
+			}
+			s_hn = hn;
+			s_cell = cell;
+		}
+		__syncthreads();
+		const int i = s_cell;
+		if (i < 0) break;
+
+		const uint32_t di = instr[i];
+		const int ddx = (int)(di & 0xFF) - 8, ddy = (int)((di >> 8) & 0xFF) - 8;
+		const uint32_t prev_prio = (di >> 16) & 0xFF, cooldown = di >> 24;
+		ushort2 xy = tb.cell_xy[i];
+		const int x = (int)xy.x + ddx, y = (int)xy.y + ddy;
+
+		uint32_t rows[10];
+		window_rows(pl, x - 1, y - 1, rows);
+
+		// (window position k in visiting order, tile t) pairs over the lanes; key = dist << 8 | k << 4 | t, min wins
+		const int nwin = (cooldown == 0xFE) ? 9 : 5;         // CimbDecoder.cpp:144
+		const int t = lane & 15;
+		uint32_t best = 0xFFFFFFFFu;
+		for (int k = lane >> 4; k < nwin; k += 4) {
+			int w = ORDER[k];
+			if ((uint32_t)w == cooldown && w != 4) continue;   // CimbDecoder.cpp:114-115
+			uint32_t d = (uint32_t)__popcll(window_hash(rows, w) ^ c_tile[t]);
+			uint32_t key = (d << 8) | ((uint32_t)k << 4) | (uint32_t)t;
+			best = key < best ? key : best;
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(best, off); best = o < best ? o : best; }
+
+		if (lane == 0) {
+			const uint32_t error_distance = best >> 8, w = (uint32_t)ORDER[(best >> 4) & 15], bits = best & 15u;
+			const int bdx = (int)(w % 3) - 1, bdy = (int)(w / 3) - 1;                 // CellDrift.h:13-15
+			int ndx = ddx + bdx, ndy = ddy + bdy;                                     // CellDrift.cpp:23-31
+			ndx = ndx > 7 ? 7 : (ndx < -7 ? -7 : ndx);
+			ndy = ndy > 7 ? 7 : (ndy < -7 ? -7 : ndy);
+			const uint32_t ncool = calc_cooldown(cooldown, w);
+
+			symbols[(size_t)f * NCELLS + i] = (uint8_t)bits;
+			drift[((size_t)f * NCELLS + i) * 2] = (int8_t)(ddx + bdx);                // CimbReader.cpp:158-160 pos.x/y
+			drift[((size_t)f * NCELLS + i) * 2 + 1] = (int8_t)(ddy + bdy);
+			if (dist_out) dist_out[(size_t)f * NCELLS + i] = (uint8_t)error_distance;
+
+			int hn = s_hn;
+			const int16_t* adj = tb.adj + (size_t)i * 4;
+			const int ar = adj[0], al = adj[1], ab = adj[2], at = adj[3];
+			offer(ar, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);   // FloodDecodePositions.cpp:85-88
+			offer(al, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+			offer(ab, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+			offer(at, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+			if (prev_prio < 3 && error_distance < 3 && cooldown == 4 && ncool == 4) {   // :93-129 "horizon"
+				if (ar >= 0 && al >= 0) {
+					int h0 = tb.adj[(size_t)ar * 4 + 0], h1 = h0 >= 0 ? tb.adj[(size_t)h0 * 4 + 0] : -1;
+					int h2 = tb.adj[(size_t)al * 4 + 1], h3 = h2 >= 0 ? tb.adj[(size_t)h2 * 4 + 1] : -1;
+					offer(h0, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(h1, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(h2, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(h3, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+				}
+				if (at >= 0 && ab >= 0) {
+					int v0 = tb.adj[(size_t)at * 4 + 3], v1 = v0 >= 0 ? tb.adj[(size_t)v0 * 4 + 3] : -1;
+					int v2 = tb.adj[(size_t)ab * 4 + 2], v3 = v2 >= 0 ? tb.adj[(size_t)v2 * 4 + 2] : -1;
+					offer(v0, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(v1, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(v2, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+					offer(v3, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
+				}
+			}
+			s_hn = hn;
+		}
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K3 Reed-Solomon
+// reed_solomon_stream.h:54-77 -> libcorrect decode.c:299-379, one 155-byte block per wavefront. The block is gathered
+// straight out of the per-cell symbol (4 bit, 2 cells/byte) or colour (2 bit, 4 cells/byte) arrays through the inverse
+// interleave map (Decoder.h:91-96,112; bitbuffer.h:62-84), so the 6200/3100-byte pre-RS streams never exist in memory.
+struct RsShared {
+	uint8_t exp[512];
+	uint8_t log[256];
+	uint8_t enc[4][160];      // block in transmit order
+	uint8_t synd[4][32];
+	uint8_t loc[4][72];
+	uint8_t last[4][72];
+	uint8_t evalr[4][32];
+};
+
+__device__ __forceinline__ uint8_t gf_mul(const RsShared& s, uint8_t l, uint8_t r) { return (!l || !r) ? 0 : s.exp[(unsigned)s.log[l] + s.log[r]]; }
+__device__ __forceinline__ uint8_t gf_div(const RsShared& s, uint8_t l, uint8_t r) { return (!l || !r) ? 0 : s.exp[255u + s.log[l] - s.log[r]]; }
+// value of sum_i coef[i] * e^i for i <= order (polynomial.c:113-131 with element_exp rows = successive powers of e), e != 0
+__device__ __forceinline__ uint8_t gf_eval(const RsShared& s, const uint8_t* coef, int order, uint8_t e)
+{
+	unsigned le = s.log[e] % 255u, acc = 0;   // log[1] == 255 -> 0
+	uint8_t res = 0;
+	for (int i = 0; i <= order; ++i) {
+		if (coef[i]) res ^= s.exp[(unsigned)s.log[coef[i]] + acc];
+		acc += le; if (acc >= 255u) acc -= 255u;
+	}
+	return res;
+}
+
+template <int BITS>   // 4: symbol stream, 2: colour stream
+__global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, Tables tb, int nframes, int first_chunk,
+                                            uint8_t* __restrict__ chunks, uint8_t* __restrict__ rs_ok, int ok_offset)
+{
+	constexpr int NBLK = (BITS == 4) ? SYM_BLOCKS : COL_BLOCKS;
+	constexpr int PER_BYTE = 8 / BITS;
+	__shared__ RsShared s;
+	for (int k = threadIdx.x; k < 512; k += 256) s.exp[k] = c_gf_exp[k];
+	s.log[threadIdx.x] = c_gf_log[threadIdx.x];
+	__syncthreads();
+
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int gb = blockIdx.x * 4 + wv;                 // global block number over the batch
+	const int f = gb / NBLK, b = gb % NBLK;
+	if (f >= nframes) return;
+	const uint8_t* cf = cells + (size_t)f * NCELLS;
+	uint8_t* enc = s.enc[wv];
+
+	// gather: stream byte B = 155*b + k packs stream cells PER_BYTE*B .. +PER_BYTE-1, first cell in the high bits
+	for (int k = lane; k < RS_BLOCK; k += 64) {
+		int sidx = (RS_BLOCK * b + k) * PER_BYTE;
+		uint32_t v = 0;
+#pragma unroll
+		for (int q = 0; q < PER_BYTE; ++q) v = (v << BITS) | (cf[tb.stream_cell[sidx + q]] & ((1u << BITS) - 1u));
+		enc[k] = (uint8_t)v;
+	}
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_s_waitcnt(0);   // lgkmcnt/vmcnt drain: LDS writes above visible to the wave's later reads
+
+	// syndromes S_j = r(alpha^(j+1)), r(x) = sum_i enc[154-i] x^i  (decode.c:12-28): Horner from the highest degree
+	if (lane < RS_PARITY) {
+		const unsigned lr = (unsigned)lane + 1u;
+		uint8_t acc = 0;
+		for (int k = 0; k < RS_BLOCK; ++k) {
+			acc = acc ? s.exp[(unsigned)s.log[acc] + lr] : 0;
+			acc ^= enc[k];
+		}
+		s.synd[wv][lane] = acc;
+	}
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_s_waitcnt(0);
+	const uint8_t mysynd = lane < RS_PARITY ? s.synd[wv][lane] : 0;
+	const bool all_zero = !__any(mysynd != 0);
+
+	int ok = 1;
+	if (!all_zero) {
+		uint8_t* loc = s.loc[wv];
+		uint8_t* last = s.last[wv];
+		const uint8_t* synd = s.synd[wv];
+		__shared__ int s_order[4];
+		if (lane == 0) {
+			// Berlekamp-Massey, decode.c:32-118, literal
+			for (int k = 0; k < 72; ++k) { loc[k] = 0; last[k] = 0; }
+			loc[0] = 1; last[0] = 1;
+			unsigned loc_order = 0, last_order = 0, numerrors = 0, delay = 1;
+			uint8_t last_disc = 1;
+			for (unsigned i = 0; i < (unsigned)RS_PARITY; ++i) {
+				uint8_t disc = synd[i];
+				for (unsigned j = 1; j <= numerrors; ++j) disc ^= gf_mul(s, loc[j], synd[i - j]);
+				if (!disc) { delay++; continue; }
+				if (2 * numerrors <= i) {
+					for (int j = (int)last_order; j >= 0; --j) last[j + delay] = gf_div(s, gf_mul(s, last[j], disc), last_disc);
+					for (int j = (int)delay - 1; j >= 0; --j) last[j] = 0;
+					for (unsigned j = 0; j <= last_order + delay; ++j) { uint8_t t = loc[j]; loc[j] ^= last[j]; last[j] = t; }
+					unsigned t_order = loc_order;
+					loc_order = last_order + delay;
+					last_order = t_order;
+					numerrors = i + 1 - numerrors;
+					last_disc = disc;
+					delay = 1;
+					continue;
+				}
+				for (int j = (int)last_order; j >= 0; --j) loc[j + delay] ^= gf_div(s, gf_mul(s, last[j], disc), last_disc);
+				loc_order = (last_order + delay > loc_order) ? last_order + delay : loc_order;
+				delay++;
+			}
+			s_order[wv] = (int)loc_order;
+		}
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_s_waitcnt(0);
+		const int order = s_order[wv];
+
+		// error evaluator = locator * S mod x^30 (decode.c:149-161, polynomial.c:17-30): coefficient k on lane k
+		if (lane < RS_PARITY) {
+			uint8_t acc = 0;
+			for (int i = 0; i <= order && i <= lane; ++i) acc ^= gf_mul(s, loc[i], synd[lane - i]);
+			s.evalr[wv][lane] = acc;
+		}
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_s_waitcnt(0);
+
+		// Chien over every field element (decode.c:122-145); element 0 evaluates to loc[0] = 1, never a root
+		int nroots = 0;
+		uint8_t myroots[4];
+		bool isroot[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			int e = lane + 64 * r;
+			bool root = false;
+			// order >= 30 would index past libcorrect's element_exp rows (undefined there); treated as "not a root"
+			if (e != 0 && order < RS_PARITY) root = gf_eval(s, loc, order, (uint8_t)e) == 0;
+			isroot[r] = root;
+			myroots[r] = (uint8_t)e;
+			nroots += __popcll(__ballot(root));
+		}
+		if (nroots != order) {
+			ok = 0;   // decode.c:354-358: too many errors
+		} else {
+			// Forney (decode.c:165-196) + locations (decode.c:198-222) + fix-up (decode.c:366-369), one root per lane-slot
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (!isroot[r]) continue;
+				const uint8_t e = myroots[r];
+				// formal derivative (polynomial.c:74-87): der[i] = (i+1 odd) ? loc[i+1] : 0, order-1
+				uint8_t num = gf_eval(s, s.evalr[wv], RS_PARITY - 1, e);
+				uint8_t den = 0;
+				{
+					unsigned le = s.log[e] % 255u, acc = 0;
+					for (int i = 0; i <= order - 1; ++i) {
+						uint8_t c = ((i + 1) & 1) ? loc[i + 1] : 0;
+						if (c) den ^= s.exp[(unsigned)s.log[c] + acc];
+						acc += le; if (acc >= 255u) acc -= 255u;
+					}
+				}
+				const uint8_t val = gf_div(s, num, den);                 // field_pow(root, fcr-1 = 0) == 1
+				const uint8_t X = gf_div(s, 1, e);                        // error location = log(1/root); log(1) aliases to j = 0 -> 0
+				const unsigned location = (X == 1) ? 0u : (unsigned)s.log[X];
+				if (location < (unsigned)RS_BLOCK) enc[RS_BLOCK - 1 - location] ^= val;   // >= 155: lands in the zero padding, not emitted
+			}
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_s_waitcnt(0);
+		}
+	}
+
+	// the 125 message bytes of block b are bytes [125*(b%5), +125) of chunk first_chunk + b/5 (aligned_stream.h:62-85)
+	uint8_t* dst = chunks + (size_t)f * FRAME_BYTES + (size_t)(first_chunk + b / 5) * CHUNK + (size_t)(b % 5) * RS_DATA;
+	for (int k = lane; k < RS_DATA; k += 64) dst[k] = enc[k];
+	if (lane == 0) rs_ok[(size_t)f * ALL_BLOCKS + ok_offset + b] = (uint8_t)ok;
+}
+
+// ------------------------------------------------------------------------------------------------ per-frame glue
+// FountainMetadata.h:16-92
+__device__ __forceinline__ uint32_t md_id(const uint8_t h[6]) { return (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24); }
+__device__ __forceinline__ unsigned md_file_size(const uint8_t h[6]) { return (unsigned)h[3] | ((unsigned)h[2] << 8) | ((unsigned)h[1] << 16) | (((unsigned)h[0] & 0x80u) << 17); }
+__device__ __forceinline__ void md_increment(uint8_t h[6], unsigned radioactive)
+{
+	unsigned next = ((unsigned)h[5] | ((unsigned)h[4] << 8)) + 1;
+	if (next == radioactive) next += 1;
+	h[4] = (uint8_t)((next >> 8) & 0xFF);
+	h[5] = (uint8_t)(next & 0xFF);
+}
+
+struct FrameState {           // aligned_stream + CimbReader metadata state carried from the symbol to the colour pass
+	uint32_t offset;          // aligned_stream::_offset
+	uint32_t bad;             // aligned_stream::_badChunk
+	uint32_t mask;            // chunks delivered so far
+	uint32_t total;           // aligned_stream::_totalCount
+};
+
+// aligned_stream.h:39-119 driven one 125-byte RS block at a time (reed_solomon_stream.h:62-74,109-114). A bad LAST block of
+// a chunk leaves _badChunk set, so the NEXT chunk is the one that gets dropped -- kept, it is what the reference does.
+// `hdr`/`radio` mirror CimbReader::update_metadata (CimbReader.cpp:269-280) when track_md is set.
+__device__ __forceinline__ void aligner_block(FrameState& st, int block_no, int ok, const uint8_t* frame_chunks, bool track_md,
+                                              uint8_t hdr[6], unsigned& radio)
+{
+	const int chunk_index = block_no / 5;
+	if (!ok) { st.bad = 1; st.offset = (st.offset + RS_DATA) % CHUNK; return; }
+	if (RS_DATA + st.offset >= (unsigned)CHUNK) {
+		const bool delivered = !st.bad;
+		if (st.bad) { st.bad = 0; st.offset = 0; }
+		else { st.mask |= 1u << chunk_index; st.total += CHUNK; st.offset = 0; }
+		if (track_md) {
+			if (!delivered && md_id(hdr) == 0) return;                       // update_metadata(nullptr, 0)
+			if (md_id(hdr) == 0) { for (int k = 0; k < 6; ++k) hdr[k] = frame_chunks[(size_t)chunk_index * CHUNK + k]; }
+			if (radio == 0) { unsigned fs = md_file_size(hdr); radio = (fs % CHUNK == 0) ? 0xFFFFFFFFu : fs / CHUNK; }
+			md_increment(hdr, radio);
+		}
+		return;
+	}
+	st.offset += RS_DATA;
+}
+
+// Cell.h:30-62 mean_rgb_continuous(skip=false) over a 6x6 block whose top-left pixel is (x, y): uint16 sums / 36
+__device__ __forceinline__ void mean6x6(const uint8_t* __restrict__ frame, int x, int y, uint32_t out[3])
+{
+	uint32_t r = 0, g = 0, b = 0;
+#pragma unroll
+	for (int i = 0; i < 6; ++i) {
+		const uint8_t* p = frame + ((size_t)(y + i) * IMG + x) * 3;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) { r += p[3 * j]; g += p[3 * j + 1]; b += p[3 * j + 2]; }
+	}
+	out[0] = (r & 0xFFFFu) / 36u; out[1] = (g & 0xFFFFu) / 36u; out[2] = (b & 0xFFFFu) / 36u;
+}
+
+// ---- float arithmetic that must match the CPU restatement operation for operation: no contraction, IEEE div/sqrt
+#pragma clang fp contract(off)
+
+// CimbReader.cpp:55-86 calculateWhite (dark): three 4x4 anchor-centre means (cv::mean -> double), max, floor (1,1,1)
+__device__ void calculate_white(const uint8_t* __restrict__ frame, float white[3])
+{
+	const int tl = ANCHOR - 2, far = IMG - ANCHOR - 2;
+	const int ax[3] = {tl, tl, far}, ay[3] = {tl, far, tl};
+	white[0] = white[1] = white[2] = 1.0f;
+	for (int a = 0; a < 3; ++a) {
+		double sm[3] = {0, 0, 0};
+		for (int i = 0; i < 4; ++i)
+			for (int j = 0; j < 4; ++j) {
+				const uint8_t* p = frame + ((size_t)(ay[a] + i) * IMG + (ax[a] + j)) * 3;
+				sm[0] += p[0]; sm[1] += p[1]; sm[2] += p[2];
+			}
+		for (int c = 0; c < 3; ++c) { float v = (float)(sm[c] / 16.0); if (v > white[c]) white[c] = v; }
+	}
+}
+
+// [assumed-OpenCV] lapack.cpp JacobiSVDImpl_<float>, n = 3 rows of length m = R (<= 5); same operation order as
+// oracle/cimbar_oracle.c jacobi_svd_f32 (hypot spelled sqrt(p*p+beta*beta) in both)
+__device__ void jacobi_svd3(float* At, int m, float* Wout, float* Vt)
+{
+	const int n = 3;
+	const double minval = FLT_MIN;
+	const float eps = FLT_EPSILON * 2;
+	double W[3];
+	const int max_iter = m > 30 ? m : 30;
+	for (int i = 0; i < n; ++i) {
+		double sd = 0;
+		for (int k = 0; k < m; ++k) { float t = At[i * m + k]; sd += (double)t * t; }
+		W[i] = sd;
+		for (int k = 0; k < n; ++k) Vt[i * n + k] = 0;
+		Vt[i * n + i] = 1;
+	}
+	for (int iter = 0; iter < max_iter; ++iter) {
+		bool changed = false;
+		for (int i = 0; i < n - 1; ++i)
+			for (int j = i + 1; j < n; ++j) {
+				float *Ai = At + i * m, *Aj = At + j * m;
+				double a = W[i], p = 0, b = W[j];
+				for (int k = 0; k < m; ++k) p += (double)Ai[k] * Aj[k];
+				if (fabs(p) <= eps * sqrt(a * b)) continue;
+				p *= 2;
+				double beta = a - b, gamma = sqrt(p * p + beta * beta);
+				float c, s;
+				if (beta < 0) {
+					double delta = (gamma - beta) * 0.5;
+					s = (float)sqrt(delta / gamma);
+					c = (float)(p / (gamma * s * 2));
+				} else {
+					c = (float)sqrt((gamma + beta) / (gamma * 2));
+					s = (float)(p / (gamma * c * 2));
+				}
+				a = b = 0;
+				for (int k = 0; k < m; ++k) {
+					float t0 = c * Ai[k] + s * Aj[k];
+					float t1 = -s * Ai[k] + c * Aj[k];
+					Ai[k] = t0; Aj[k] = t1;
+					a += (double)t0 * t0; b += (double)t1 * t1;
+				}
+				W[i] = a; W[j] = b;
+				changed = true;
+				float *Vi = Vt + i * n, *Vj = Vt + j * n;
+				for (int k = 0; k < n; ++k) {
+					float t0 = c * Vi[k] + s * Vj[k];
+					float t1 = -s * Vi[k] + c * Vj[k];
+					Vi[k] = t0; Vj[k] = t1;
+				}
+			}
+		if (!changed) break;
+	}
+	for (int i = 0; i < n; ++i) {
+		double sd = 0;
+		for (int k = 0; k < m; ++k) { float t = At[i * m + k]; sd += (double)t * t; }
+		W[i] = sqrt(sd);
+	}
+	for (int i = 0; i < n - 1; ++i) {
+		int j = i;
+		for (int k = i + 1; k < n; ++k) if (W[j] < W[k]) j = k;
+		if (i != j) {
+			double tw = W[i]; W[i] = W[j]; W[j] = tw;
+			for (int k = 0; k < m; ++k) { float t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+			for (int k = 0; k < n; ++k) { float t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
+		}
+	}
+	for (int i = 0; i < n; ++i) Wout[i] = (float)W[i];
+	for (int i = 0; i < n; ++i) {
+		double sd = W[i];
+		float s = (float)(sd > minval ? 1 / sd : 0.);
+		for (int k = 0; k < m; ++k) At[i * m + k] *= s;
+	}
+}
+
+// color_correction.h:26-39 get_moore_penrose_lsm: ccm = desired^T * pinv(actual^T) [assumed-OpenCV: SVD + SVBkSb + gemm]
+__device__ void moore_penrose_lsm(const float* actual, const float* desired, int R, float ccm[9])
+{
+	float A[15], V[9], W[3];
+	for (int i = 0; i < 3; ++i) for (int k = 0; k < R; ++k) A[i * R + k] = actual[k * 3 + i];
+	jacobi_svd3(A, R, W, V);
+	float z[15];
+	for (int i = 0; i < R * 3; ++i) z[i] = 0;
+	double threshold = 0;
+	for (int i = 0; i < 3; ++i) threshold += W[i];
+	threshold *= (double)(FLT_EPSILON * 2);
+	for (int k = 0; k < 3; ++k) {
+		double wi = W[k];
+		if (fabs(wi) <= threshold) continue;
+		wi = 1 / wi;
+		double buffer[3];
+		for (int j = 0; j < 3; ++j) buffer[j] = V[k * 3 + j] * wi;
+		for (int i = 0; i < R; ++i) {
+			float s = A[k * R + i];
+			for (int j = 0; j < 3; ++j) z[i * 3 + j] = (float)(z[i * 3 + j] + s * buffer[j]);
+		}
+	}
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			double sm = 0;
+			for (int k = 0; k < R; ++k) sm += (double)desired[k * 3 + i] * (double)z[k * 3 + j];
+			ccm[i * 3 + j] = (float)sm;
+		}
+}
+
+// color_correction.h:11-24 get_adaptation_matrix<von_kries>(white, (255,255,255)) -- color_correction == 1
+__device__ void von_kries_ccm(const float white[3], float out[9])
+{
+	const float T[9] = {0.4002400f, 0.7076000f, -0.0808100f, -0.2263000f, 1.1653200f, 0.0457000f, 0.0000000f, 0.0000000f, 0.9182200f};
+	float m1[3], m2[3], d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ti[9], tmp[9];
+	for (int i = 0; i < 3; ++i) {
+		float s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * white[k]; m1[i] = s;
+		float q = 0; for (int k = 0; k < 3; ++k) q += T[i * 3 + k] * 255.0f; m2[i] = q;
+	}
+	for (int i = 0; i < 3; ++i) d[i * 3 + i] = m2[i] / m1[i];
+#define A_(i, j) T[(i) * 3 + (j)]
+	float det = (float)(A_(0,0) * (A_(1,1) * A_(2,2) - A_(2,1) * A_(1,2)) - A_(0,1) * (A_(1,0) * A_(2,2) - A_(2,0) * A_(1,2)) +
+	                    A_(0,2) * (A_(1,0) * A_(2,1) - A_(2,0) * A_(1,1)));
+	det = 1 / det;
+	ti[0] = (A_(1,1) * A_(2,2) - A_(1,2) * A_(2,1)) * det; ti[1] = (A_(0,2) * A_(2,1) - A_(0,1) * A_(2,2)) * det;
+	ti[2] = (A_(0,1) * A_(1,2) - A_(0,2) * A_(1,1)) * det; ti[3] = (A_(1,2) * A_(2,0) - A_(1,0) * A_(2,2)) * det;
+	ti[4] = (A_(0,0) * A_(2,2) - A_(0,2) * A_(2,0)) * det; ti[5] = (A_(0,2) * A_(1,0) - A_(0,0) * A_(1,2)) * det;
+	ti[6] = (A_(1,0) * A_(2,1) - A_(1,1) * A_(2,0)) * det; ti[7] = (A_(0,1) * A_(2,0) - A_(0,0) * A_(2,1)) * det;
+	ti[8] = (A_(0,0) * A_(1,1) - A_(0,1) * A_(1,0)) * det;
+#undef A_
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += ti[i * 3 + k] * d[k * 3 + j]; tmp[i * 3 + j] = s; }
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += tmp[i * 3 + k] * T[k * 3 + j]; out[i * 3 + j] = s; }
+}
+
+// CimbDecoder.cpp:168-200 get_best_color (+ :27-55, color_correction.h:64-68)
+__device__ __forceinline__ uint32_t fix_single_color(float c, float adjust_up, float down)
+{
+	c -= down;
+	c *= adjust_up;
+	if (c > (245 - down)) c = 255;
+	if (c < 0) c = 0;
+	return (uint32_t)c & 0xFFu;
+}
+__device__ __forceinline__ uint32_t best_color(float r, float g, float b, const float* m, bool active)
+{
+	if (active) {
+		float s0 = 0, s1 = 0, s2 = 0;
+		s0 += m[0] * r; s0 += m[1] * g; s0 += m[2] * b;
+		s1 += m[3] * r; s1 += m[4] * g; s1 += m[5] * b;
+		s2 += m[6] * r; s2 += m[7] * g; s2 += m[8] * b;
+		r = s0; g = s1; b = s2;
+	}
+	float mx = r; if (g > mx) mx = g; if (b > mx) mx = b; if (1.0f > mx) mx = 1.0f;
+	float mn = r; if (g < mn) mn = g; if (b < mn) mn = b; if (48.0f < mn) mn = 48.0f;
+	if (mn >= mx) mn = 0;
+	float adjust = (float)(255.0 / (double)(mx - mn));
+	int c0 = (int)fix_single_color(r, adjust, mn), c1 = (int)fix_single_color(g, adjust, mn), c2 = (int)fix_single_color(b, adjust, mn);
+	int rel0 = c0 - c1, rel1 = c1 - c2, rel2 = c2 - c0;
+	uint32_t best_fit = 0, best_distance = 1000000u;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		int q0 = c_palette[i][0] - c_palette[i][1], q1 = c_palette[i][1] - c_palette[i][2], q2 = c_palette[i][2] - c_palette[i][0];
+		uint32_t d = (uint32_t)((rel0 - q0) * (rel0 - q0) + (rel1 - q1) * (rel1 - q1) + (rel2 - q2) * (rel2 - q2));
+		if (d < best_distance) { best_fit = (uint32_t)i; best_distance = d; }
+	}
+	return best_fit;
+}
+#pragma clang fp contract(fast)
+
+// K4: one wavefront per frame, after the symbol RS pass. Runs the chunk bookkeeping for blocks 0..39, then
+// CimbReader::init_ccm (CimbReader.cpp:169-267) for color_correction == 2, or the von Kries matrix for == 1.
+// ccm_out[f] = {9 floats, valid}; valid == 0 means "keep whatever the thread had" (resolved in k_colors).
+__global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rgb, Tables tb, const uint8_t* __restrict__ chunks,
+                                                  const uint8_t* __restrict__ rs_ok, int color_correction,
+                                                  FrameState* __restrict__ states, float* __restrict__ ccm_out)
+{
+	const int f = blockIdx.x, lane = threadIdx.x;
+	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
+	const uint8_t* fc = chunks + (size_t)f * FRAME_BYTES;
+	__shared__ uint8_t s_hdr[4][6];      // predicted header of colour chunk c (CimbReader.cpp:188-227)
+	__shared__ int s_have_hdr;
+	__shared__ uint32_t s_cnt[4], s_r[4], s_g[4], s_b[4], s_first[4];
+
+	if (lane == 0) {
+		FrameState st = {0, 0, 0, 0};
+		uint8_t hdr[6] = {0, 0, 0, 0, 0, 0};
+		unsigned radio = 0;
+		for (int b = 0; b < SYM_BLOCKS; ++b) aligner_block(st, b, rs_ok[(size_t)f * ALL_BLOCKS + b], fc, true, hdr, radio);
+		states[f] = st;
+		s_have_hdr = md_id(hdr) != 0;
+		for (int c = 0; c < 4; ++c) {
+			for (int k = 0; k < 6; ++k) s_hdr[c][k] = hdr[k];
+			md_increment(hdr, radio);
+		}
+	}
+	if (lane < 4) { s_cnt[lane] = 0; s_r[lane] = 0; s_g[lane] = 0; s_b[lane] = 0; s_first[lane] = 0xFFFFFFFFu; }
+	__syncthreads();
+
+	float* out = ccm_out + (size_t)f * 10;
+	if (color_correction == 1) {
+		if (lane == 0) {
+			float white[3], m[9];
+			calculate_white(frame, white);
+			von_kries_ccm(white, m);
+			for (int k = 0; k < 9; ++k) out[k] = m[k];
+			out[9] = 1.0f;
+		}
+		return;
+	}
+	if (color_correction != 2 || !s_have_hdr) {
+		if (lane == 0) out[9] = 0.0f;
+		return;
+	}
+
+	// 96 known-colour cells: colour-stream cells 3100*c + t, t < 24; expected colour = bits [2t, 2t+2) of header c
+	for (int q = lane; q < 96; q += 64) {
+		const int c = q / 24, t = q % 24;
+		const uint32_t expected = ((uint32_t)s_hdr[c][t >> 2] >> (6 - 2 * (t & 3))) & 3u;
+		const int cell = tb.stream_cell[3100 * c + t];
+		ushort2 xy = tb.cell_xy[cell];
+		uint32_t col[3];
+		mean6x6(frame, (int)xy.x + 1, (int)xy.y + 1, col);   // undrifted grid position + 1 (CimbReader.cpp:216-217)
+		atomicAdd(&s_cnt[expected], 1u);
+		atomicAdd(&s_r[expected], col[0]);
+		atomicAdd(&s_g[expected], col[1]);
+		atomicAdd(&s_b[expected], col[2]);
+		atomicMin(&s_first[expected], (uint32_t)q);
+	}
+	__syncthreads();
+
+	if (lane == 0) {
+		// rows in std::unordered_map iteration order = reverse order of first appearance (libstdc++)
+		float actual[15], desired[15];
+		int rows = 0;
+		uint32_t used = 0;
+		for (int pass = 0; pass < 4; ++pass) {
+			int bestc = -1; uint32_t bestq = 0;
+			for (int c = 0; c < 4; ++c)
+				if (!(used & (1u << c)) && s_cnt[c] != 0 && (bestc < 0 || s_first[c] > bestq)) { bestc = c; bestq = s_first[c]; }
+			if (bestc < 0) break;
+			used |= 1u << bestc;
+			actual[rows * 3] = (float)(s_r[bestc] / s_cnt[bestc]);
+			actual[rows * 3 + 1] = (float)(s_g[bestc] / s_cnt[bestc]);
+			actual[rows * 3 + 2] = (float)(s_b[bestc] / s_cnt[bestc]);
+			desired[rows * 3] = (float)c_palette[bestc][0]; desired[rows * 3 + 1] = (float)c_palette[bestc][1]; desired[rows * 3 + 2] = (float)c_palette[bestc][2];
+			++rows;
+		}
+		if (rows < 4) { out[9] = 0.0f; return; }
+		float white[3], m[9];
+		calculate_white(frame, white);
+		actual[rows * 3] = white[0]; actual[rows * 3 + 1] = white[1]; actual[rows * 3 + 2] = white[2];
+		desired[rows * 3] = desired[rows * 3 + 1] = desired[rows * 3 + 2] = 255.0f;
+		++rows;
+		moore_penrose_lsm(actual, desired, rows, m);
+		for (int k = 0; k < 9; ++k) out[k] = m[k];
+		out[9] = 1.0f;
+	}
+}
+
+// K5: colour pass (Decoder.h:107-113; CimbReader.cpp:133-137; CimbDecoder.cpp:202-217). The matrix in force for frame
+// f is the newest valid one among frames <= f of this batch, else the context's carried one (slot `carry`).
+__global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb, Tables tb, const float* __restrict__ ccm_frames,
+                                                const float* __restrict__ carry, const uint32_t* __restrict__ flood_flag,
+                                                const int8_t* __restrict__ drift, uint8_t* __restrict__ colors,
+                                                float* __restrict__ ccm_used)
+{
+	const int f = blockIdx.y;
+	__shared__ float s_m[10];
+	if (threadIdx.x == 0) {
+		int g = f;
+		while (g >= 0 && ccm_frames[(size_t)g * 10 + 9] == 0.0f) --g;
+		const float* src = g >= 0 ? ccm_frames + (size_t)g * 10 : carry;
+		for (int k = 0; k < 10; ++k) s_m[k] = src[k];
+		if (blockIdx.x == 0) for (int k = 0; k < 10; ++k) ccm_used[(size_t)f * 10 + k] = src[k];
+	}
+	__syncthreads();
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= NCELLS) return;
+	ushort2 xy = tb.cell_xy[i];
+	int x = (int)xy.x, y = (int)xy.y;
+	if (flood_flag[f]) { x += drift[((size_t)f * NCELLS + i) * 2]; y += drift[((size_t)f * NCELLS + i) * 2 + 1]; }
+	uint32_t col[3];
+	mean6x6(rgb + (size_t)f * FRAME_RGB, x + 1, y + 1, col);
+	colors[(size_t)f * NCELLS + i] = (uint8_t)best_color((float)col[0], (float)col[1], (float)col[2], s_m, s_m[9] != 0.0f);
+}
+
+// K7: chunk bookkeeping for the colour blocks, final mask, zero the slots of dropped chunks, per-frame good bytes
+__global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
+                                                  uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
+                                                  unsigned long long* __restrict__ total_good)
+{
+	const int f = blockIdx.x, lane = threadIdx.x;
+	__shared__ uint32_t s_mask;
+	if (lane == 0) {
+		FrameState st = states[f];
+		uint8_t hdr[6] = {0, 0, 0, 0, 0, 0};
+		unsigned radio = 0;
+		for (int b = 0; b < COL_BLOCKS; ++b) aligner_block(st, SYM_BLOCKS + b, rs_ok[(size_t)f * ALL_BLOCKS + SYM_BLOCKS + b], nullptr, false, hdr, radio);
+		states[f] = st;
+		masks[f] = st.mask;
+		s_mask = st.mask;
+		atomicAdd(total_good, (unsigned long long)st.total);
+	}
+	__syncthreads();
+	const uint32_t mask = s_mask;
+	uint8_t* fc = chunks + (size_t)f * FRAME_BYTES;
+	for (int j = 0; j < CHUNKS; ++j)
+		if (!(mask & (1u << j)))
+			for (int k = lane; k < CHUNK; k += 64) fc[(size_t)j * CHUNK + k] = 0;
+}
+
+// carried CCM after the batch = the matrix in force for its last frame
+__global__ void k_ccm_carry(const float* __restrict__ ccm_used, int last, float* __restrict__ carry)
+{
+	if (threadIdx.x < 10) carry[threadIdx.x] = ccm_used[(size_t)last * 10 + threadIdx.x];
+}
+
+// repack the internal word-oriented bitplane into CimbReader::_grayscale's byte layout (tap only)
+__global__ void k_plane_bytes(const uint32_t* __restrict__ plane, uint8_t* __restrict__ out, size_t nwords)
+{
+	size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= nwords) return;
+	uint32_t v = plane[w];
+	out[4 * w] = (uint8_t)(v >> 24); out[4 * w + 1] = (uint8_t)(v >> 16); out[4 * w + 2] = (uint8_t)(v >> 8); out[4 * w + 3] = (uint8_t)v;
+}
+
+}  // namespace
+
+// ================================================================================================ host side / C ABI
+struct cimbar_hip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	Tables tb{};
+	// batch scratch (grown on demand)
+	int cap = 0;
+	int last_n = 0;
+	uint8_t* d_rgb = nullptr;         // staging for host-resident input
+	size_t d_rgb_cap = 0;
+	uint32_t* d_plane = nullptr;
+	uint8_t* d_symbols = nullptr;
+	uint8_t* d_colors = nullptr;
+	uint8_t* d_dist = nullptr;
+	int8_t* d_drift = nullptr;
+	uint32_t* d_flood = nullptr;
+	uint8_t* d_rs_ok = nullptr;
+	FrameState* d_states = nullptr;
+	float* d_ccm_frames = nullptr;
+	float* d_ccm_used = nullptr;
+	float* d_carry = nullptr;         // 10 floats
+	uint8_t* d_chunks = nullptr;      // staging for host-resident output
+	uint32_t* d_masks = nullptr;
+	unsigned long long* d_total = nullptr;
+	FloodScratch flood{};
+	int flood_cap = 0;
+	// timing
+	bool timing = false;
+	static constexpr int NSTAGE = 9;
+	hipEvent_t ev[NSTAGE + 1] = {};
+	float stage_ms[NSTAGE] = {};
+};
+
+namespace {
+
+const char* const STAGE_NAMES[cimbar_hip_ctx::NSTAGE] = {"threshold", "symbols", "flood", "rs_symbols", "frame_mid", "colors", "rs_colors", "frame_end", "ccm_carry"};
+
+#define HIPCHK(call)                                                                                      \
+	do {                                                                                                  \
+		hipError_t e__ = (call);                                                                          \
+		if (e__ != hipSuccess) {                                                                          \
+			ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                                \
+			return CIMBAR_HIP_EHIP;                                                                       \
+		}                                                                                                 \
+	} while (0)
+
+void host_cell_positions(std::vector<ushort2>& xy)
+{
+	// CellPositions.cpp:5-51 compute_linear for Conf8x8
+	xy.resize(NCELLS);
+	int n = 0;
+	for (int i = 0; i < TOP_CELLS; ++i, ++n) xy[n] = make_ushort2((i % TOP_W) * PITCH + PITCH * MARKER + OFFSET, (i / TOP_W) * PITCH + OFFSET);
+	for (int i = 0; i < MID_CELLS; ++i, ++n) xy[n] = make_ushort2((i % DIM) * PITCH + OFFSET, (i / DIM) * PITCH + MARKER * PITCH + OFFSET);
+	for (int i = 0; i < TOP_CELLS; ++i, ++n) xy[n] = make_ushort2((i % TOP_W) * PITCH + PITCH * MARKER + OFFSET, (i / TOP_W) * PITCH + (DIM - MARKER) * PITCH + OFFSET);
+}
+
+// AdjacentCellFinder.cpp:16-105 expressed on (band, row, col) instead of position look-ups
+struct Grid {
+	static int row_of(int i) { return i < TOP_CELLS ? i / TOP_W : (i < TOP_CELLS + MID_CELLS ? MARKER + (i - TOP_CELLS) / DIM : DIM - MARKER + (i - TOP_CELLS - MID_CELLS) / TOP_W); }
+	static int col_of(int i) { return i < TOP_CELLS ? MARKER + i % TOP_W : (i < TOP_CELLS + MID_CELLS ? (i - TOP_CELLS) % DIM : MARKER + (i - TOP_CELLS - MID_CELLS) % TOP_W); }
+	static int index_of(int row, int col)
+	{
+		if (row < 0 || row >= DIM || col < 0 || col >= DIM) return -1;
+		bool margin = row < MARKER || row >= DIM - MARKER;
+		if (margin && (col < MARKER || col >= DIM - MARKER)) return -1;
+		if (row < MARKER) return row * TOP_W + (col - MARKER);
+		if (row < DIM - MARKER) return TOP_CELLS + (row - MARKER) * DIM + col;
+		return TOP_CELLS + MID_CELLS + (row - (DIM - MARKER)) * TOP_W + (col - MARKER);
+	}
+};
+
+int build_tables(cimbar_hip_ctx* ctx)
+{
+	std::vector<ushort2> xy;
+	host_cell_positions(xy);
+	// Interleave.h:8-24 interleave_indices(12400, 155, 2): stream index -> linear cell index
+	std::vector<uint16_t> sc;
+	sc.reserve(NCELLS);
+	const int part_size = NCELLS / 2;
+	for (int part = 0; part < NCELLS; part += part_size)
+		for (int chunk = 0; chunk < RS_BLOCK; ++chunk)
+			for (int i = chunk; i < part_size; i += RS_BLOCK) sc.push_back((uint16_t)(i + part));
+	std::vector<int16_t> adj((size_t)NCELLS * 4);
+	for (int i = 0; i < NCELLS; ++i) {
+		int r = Grid::row_of(i), c = Grid::col_of(i);
+		adj[(size_t)i * 4 + 0] = (int16_t)Grid::index_of(r, c + 1);
+		adj[(size_t)i * 4 + 1] = (int16_t)Grid::index_of(r, c - 1);
+		adj[(size_t)i * 4 + 2] = (int16_t)Grid::index_of(r + 1, c);
+		adj[(size_t)i * 4 + 3] = (int16_t)Grid::index_of(r - 1, c);
+	}
+	// GF(2^8) tables, libcorrect field.h:26-62 with primitive polynomial 0x187 (correct.h:159-160)
+	uint8_t gexp[512], glog[256];
+	unsigned element = 1;
+	gexp[0] = 1; glog[0] = 0;
+	for (unsigned i = 1; i < 512; ++i) {
+		element *= 2;
+		if (element > 255) element ^= 0x187;
+		gexp[i] = (uint8_t)element;
+		if (i < 256) glog[element] = (uint8_t)i;
+	}
+	HIPCHK(hipMalloc(&ctx->tb.cell_xy, sizeof(ushort2) * NCELLS));
+	HIPCHK(hipMalloc(&ctx->tb.stream_cell, sizeof(uint16_t) * NCELLS));
+	HIPCHK(hipMalloc(&ctx->tb.adj, sizeof(int16_t) * NCELLS * 4));
+	HIPCHK(hipMemcpy(ctx->tb.cell_xy, xy.data(), sizeof(ushort2) * NCELLS, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ctx->tb.stream_cell, sc.data(), sizeof(uint16_t) * NCELLS, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ctx->tb.adj, adj.data(), sizeof(int16_t) * NCELLS * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_exp), gexp, 512));
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_log), glog, 256));
+	return 0;
+}
+
+template <typename T>
+hipError_t regrow(T*& p, size_t count)
+{
+	if (p) { hipError_t e = hipFree(p); p = nullptr; if (e != hipSuccess) return e; }
+	return hipMalloc(&p, sizeof(T) * count);
+}
+
+int ensure_capacity(cimbar_hip_ctx* ctx, int n)
+{
+	if (n <= ctx->cap) return 0;
+	size_t N = (size_t)n;
+	HIPCHK(regrow(ctx->d_plane, N * PLANE_WORDS));
+	HIPCHK(regrow(ctx->d_symbols, N * NCELLS));
+	HIPCHK(regrow(ctx->d_colors, N * NCELLS));
+	HIPCHK(regrow(ctx->d_dist, N * NCELLS));
+	HIPCHK(regrow(ctx->d_drift, N * NCELLS * 2));
+	HIPCHK(regrow(ctx->d_flood, N));
+	HIPCHK(regrow(ctx->d_rs_ok, N * ALL_BLOCKS));
+	HIPCHK(regrow(ctx->d_states, N));
+	HIPCHK(regrow(ctx->d_ccm_frames, N * 10));
+	HIPCHK(regrow(ctx->d_ccm_used, N * 10));
+	HIPCHK(regrow(ctx->d_chunks, N * FRAME_BYTES));
+	HIPCHK(regrow(ctx->d_masks, N));
+	HIPCHK(regrow(ctx->flood.heap, N * HEAP_CAP));
+	HIPCHK(regrow(ctx->flood.instr, N * NCELLS));
+	HIPCHK(regrow(ctx->flood.remaining, N * NCELLS));
+	ctx->cap = n;
+	return 0;
+}
+
+void destroy_ctx(cimbar_hip_ctx* ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	auto fr = [](void* p) { if (p) (void)hipFree(p); };
+	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.adj);
+	fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
+	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
+	fr(ctx->d_masks); fr(ctx->d_total); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
+	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+// enqueue the whole pipeline for n device-resident frames
+int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks)
+{
+	const bool tm = ctx->timing;
+	int evi = 0;
+	auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(ctx->ev[evi++], st) : hipSuccess; };
+	const dim3 cell_grid((NCELLS + 255) / 256, n);
+
+	HIPCHK(hipMemsetAsync(ctx->d_flood, 0, sizeof(uint32_t) * (size_t)n, st));
+	HIPCHK(hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), st));
+	HIPCHK(mark());
+	{
+		dim3 g(IMG / K1_ROWS / 4, n);
+		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane);
+		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane);
+	}
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_symbols, cell_grid, dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood);
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_flood, dim3(n), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols, ctx->d_drift, ctx->d_dist);
+	HIPCHK(mark());
+	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, n, 0, d_chunks, ctx->d_rs_ok, 0);
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames);
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used);
+	HIPCHK(mark());
+	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total);
+	HIPCHK(mark());
+	hipLaunchKernelGGL(k_ccm_carry, dim3(1), dim3(64), 0, st, ctx->d_ccm_used, n - 1, ctx->d_carry);
+	HIPCHK(mark());
+	HIPCHK(hipGetLastError());
+	ctx->last_n = n;
+	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cimbar_hip_bufsize(void) { return FRAME_BYTES; }
+
+int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out)
+{
+	if (!out) return CIMBAR_HIP_EINVAL;
+	*out = nullptr;
+	if (mode_val != 0 && mode_val != 68) return CIMBAR_HIP_EINVAL;   // Config.h:19-44: only Conf8x8 ("B") is implemented
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CIMBAR_HIP_ENODEVICE;
+	if (hipSetDevice(device) != hipSuccess) return CIMBAR_HIP_ENODEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CIMBAR_HIP_ENODEVICE;
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CIMBAR_HIP_ENODEVICE;   // kernels are built for gfx950 only
+
+	cimbar_hip_ctx* ctx = new cimbar_hip_ctx();
+	ctx->device = device;
+	auto fail = [&](int code) { destroy_ctx(ctx); return code; };
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (hipMalloc(&ctx->d_carry, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_ENOMEM);
+	if (hipMemset(ctx->d_carry, 0, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (hipMalloc(&ctx->d_total, sizeof(unsigned long long)) != hipSuccess) return fail(CIMBAR_HIP_ENOMEM);
+	if (build_tables(ctx) != 0) return fail(CIMBAR_HIP_EHIP);
+	*out = ctx;
+	return CIMBAR_HIP_OK;
+}
+
+void cimbar_hip_destroy(cimbar_hip_ctx* ctx) { destroy_ctx(ctx); }
+
+const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipMemsetAsync(ctx->d_carry, 0, sizeof(float) * 10, ctx->stream));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	return 0;
+}
+
+int cimbar_hip_get_ccm(cimbar_hip_ctx* ctx, float out9[9])
+{
+	if (!ctx || !out9) return CIMBAR_HIP_EINVAL;
+	float tmp[10];
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipStreamSynchronize(ctx->stream));
+	HIPCHK(hipMemcpy(tmp, ctx->d_carry, sizeof tmp, hipMemcpyDeviceToHost));
+	std::memcpy(out9, tmp, sizeof(float) * 9);
+	return tmp[9] != 0.0f ? 1 : 0;
+}
+
+int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
+                                int color_correction, uint8_t* chunks, uint32_t* masks, int out_mem, void* hip_stream)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (!rgb || !chunks || !masks || n <= 0) { ctx->err = "decode_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	if (int r = ensure_capacity(ctx, n)) return r;
+
+	const uint8_t* d_rgb = rgb;
+	if (rgb_mem == CIMBAR_HIP_MEM_HOST) {
+		size_t need = (size_t)n * FRAME_RGB;
+		if (need > ctx->d_rgb_cap) { HIPCHK(regrow(ctx->d_rgb, need)); ctx->d_rgb_cap = need; }
+		HIPCHK(hipMemcpyAsync(ctx->d_rgb, rgb, need, hipMemcpyHostToDevice, st));
+		d_rgb = ctx->d_rgb;
+	}
+	uint8_t* d_chunks = out_mem == CIMBAR_HIP_MEM_DEVICE ? chunks : ctx->d_chunks;
+	uint32_t* d_masks = out_mem == CIMBAR_HIP_MEM_DEVICE ? masks : ctx->d_masks;
+
+	if (int r = enqueue(ctx, st, d_rgb, n, should_preprocess, color_correction, d_chunks, d_masks)) return r;
+
+	if (out_mem == CIMBAR_HIP_MEM_DEVICE) return 0;
+	unsigned long long total = 0;
+	HIPCHK(hipMemcpyAsync(chunks, d_chunks, (size_t)n * FRAME_BYTES, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(masks, d_masks, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (ctx->timing)
+		for (int k = 0; k < cimbar_hip_ctx::NSTAGE; ++k) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[k], ctx->ev[k], ctx->ev[k + 1]));
+	return (int64_t)total;
+}
+
+int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
+                            int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (!rgb || !chunks || !good_mask) { ctx->err = "decode_frame: null buffer"; return CIMBAR_HIP_EINVAL; }
+	if (width != (unsigned)IMG || height != (unsigned)IMG) { ctx->err = "decode_frame: frame must be 1024x1024 RGB8"; return CIMBAR_HIP_EDIM; }
+	if (stride == (size_t)IMG * 3 || stride == 0)
+		return (int)cimbar_hip_decode_batch(ctx, rgb, 1, CIMBAR_HIP_MEM_HOST, should_preprocess, color_correction, chunks, good_mask, CIMBAR_HIP_MEM_HOST, nullptr);
+	if (stride < (size_t)IMG * 3) { ctx->err = "decode_frame: stride < width*3"; return CIMBAR_HIP_EINVAL; }
+	std::vector<uint8_t> packed(FRAME_RGB);
+	for (int y = 0; y < IMG; ++y) std::memcpy(packed.data() + (size_t)y * IMG * 3, rgb + (size_t)y * stride, (size_t)IMG * 3);
+	return (int)cimbar_hip_decode_batch(ctx, packed.data(), 1, CIMBAR_HIP_MEM_HOST, should_preprocess, color_correction, chunks, good_mask, CIMBAR_HIP_MEM_HOST, nullptr);
+}
+
+int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes)
+{
+	if (!ctx || !out) return CIMBAR_HIP_EINVAL;
+	HIPCHK(hipSetDevice(ctx->device));
+	HIPCHK(hipDeviceSynchronize());
+	const size_t n = (size_t)ctx->last_n;
+	const void* src = nullptr;
+	size_t bytes = 0;
+	switch (what) {
+		case CIMBAR_HIP_TAP_BITPLANE: {
+			bytes = n * PLANE_WORDS * 4;
+			if (out_bytes < bytes) { ctx->err = "tap: buffer too small"; return CIMBAR_HIP_EINVAL; }
+			uint8_t* tmp = nullptr;
+			HIPCHK(hipMalloc(&tmp, bytes));
+			size_t nw = n * PLANE_WORDS;
+			hipLaunchKernelGGL(k_plane_bytes, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_plane, tmp, nw);
+			hipError_t e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			(void)hipFree(tmp);
+			HIPCHK(e);
+			return (int64_t)bytes;
+		}
+		case CIMBAR_HIP_TAP_SYMBOLS: src = ctx->d_symbols; bytes = n * NCELLS; break;
+		case CIMBAR_HIP_TAP_COLORS: src = ctx->d_colors; bytes = n * NCELLS; break;
+		case CIMBAR_HIP_TAP_DRIFT: src = ctx->d_drift; bytes = n * NCELLS * 2; break;
+		case CIMBAR_HIP_TAP_RS_OK: src = ctx->d_rs_ok; bytes = n * ALL_BLOCKS; break;
+		case CIMBAR_HIP_TAP_CCM: src = ctx->d_ccm_used; bytes = n * 10 * sizeof(float); break;
+		case CIMBAR_HIP_TAP_FLOOD: {
+			bytes = n;
+			if (out_bytes < bytes) { ctx->err = "tap: buffer too small"; return CIMBAR_HIP_EINVAL; }
+			std::vector<uint32_t> tmp(n);
+			HIPCHK(hipMemcpy(tmp.data(), ctx->d_flood, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+			for (size_t k = 0; k < n; ++k) ((uint8_t*)out)[k] = tmp[k] ? 1 : 0;
+			return (int64_t)bytes;
+		}
+		default: ctx->err = "tap: unknown selector"; return CIMBAR_HIP_EINVAL;
+	}
+	if (out_bytes < bytes) { ctx->err = "tap: buffer too small"; return CIMBAR_HIP_EINVAL; }
+	HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+	if (what == CIMBAR_HIP_TAP_DRIFT) {
+		// frames that took the parallel path never wrote their (all-zero) drift
+		std::vector<uint32_t> fl(n);
+		HIPCHK(hipMemcpy(fl.data(), ctx->d_flood, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+		for (size_t k = 0; k < n; ++k) if (!fl[k]) std::memset((uint8_t*)out + k * NCELLS * 2, 0, (size_t)NCELLS * 2);
+	}
+	return (int64_t)bytes;
+}
+
+int cimbar_hip_enable_timing(cimbar_hip_ctx* ctx, int on)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	ctx->timing = on != 0;
+	return 0;
+}
+
+int cimbar_hip_stage_times(cimbar_hip_ctx* ctx, const char** names, float* ms, int max)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (ctx->timing && ctx->last_n > 0) {
+		// device-output batches do not synchronise inside decode_batch; resolve the events here
+		HIPCHK(hipEventSynchronize(ctx->ev[cimbar_hip_ctx::NSTAGE]));
+		for (int k = 0; k < cimbar_hip_ctx::NSTAGE; ++k) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[k], ctx->ev[k], ctx->ev[k + 1]));
+	}
+	int k = 0;
+	for (; k < cimbar_hip_ctx::NSTAGE && k < max; ++k) {
+		if (names) names[k] = STAGE_NAMES[k];
+		if (ms) ms[k] = ctx->stage_ms[k];
+	}
+	return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+"""ctypes binding of the C ABI in include/cimbar_hip.h (plumbing for tests / bench.py / the multi-GPU driver).
+
+Mirrors the reference's Decoder surface for the hot path (src/lib/encoder/Decoder.h:16-38):
+`HipDecoder.decode_fountain(img, sink, should_preprocess, color_correction)` writes the good chunks to `sink.write` in chunk
+order and returns the good byte count, exactly what `Decoder::decode_fountain` does through aligned_stream.
+
+There is deliberately no CPU fallback: if the shared library or a gfx950 device is missing, loading/creating raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import modeb
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcimbar_hip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM = range(7)
+
+# every symbol include/cimbar_hip.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
+EXPORTS = (
+    "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
+    "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
+    "cimbar_hip_stage_times",
+)
+
+
+class CimbarHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libcimbar_hip.so and declare the prototypes. Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise CimbarHipError(f"{p} not found: build it with `python -m libcimbar_amd.build` (hipcc, gfx950). "
+                             "There is no CPU fallback for the decode path.")
+    lib = ctypes.CDLL(p)
+    vp, i32, u32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int64, ctypes.c_size_t
+    lib.cimbar_hip_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    lib.cimbar_hip_create.restype = i32
+    lib.cimbar_hip_destroy.argtypes = [vp]
+    lib.cimbar_hip_destroy.restype = None
+    lib.cimbar_hip_bufsize.argtypes = []
+    lib.cimbar_hip_bufsize.restype = i32
+    lib.cimbar_hip_last_error.argtypes = [vp]
+    lib.cimbar_hip_last_error.restype = ctypes.c_char_p
+    lib.cimbar_hip_decode_frame.argtypes = [vp, vp, u32, u32, sz, i32, i32, vp, ctypes.POINTER(ctypes.c_uint32)]
+    lib.cimbar_hip_decode_frame.restype = i32
+    lib.cimbar_hip_decode_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_decode_batch.restype = i64
+    lib.cimbar_hip_reset_ccm.argtypes = [vp]
+    lib.cimbar_hip_reset_ccm.restype = i32
+    lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.cimbar_hip_get_ccm.restype = i32
+    lib.cimbar_hip_tap.argtypes = [vp, i32, vp, sz]
+    lib.cimbar_hip_tap.restype = i64
+    lib.cimbar_hip_enable_timing.argtypes = [vp, i32]
+    lib.cimbar_hip_enable_timing.restype = i32
+    lib.cimbar_hip_stage_times.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]
+    lib.cimbar_hip_stage_times.restype = i32
+    if path is None:
+        _lib = lib
+    return lib
+
+
+_ERR = {-1: "EINVAL", -2: "EDIM", -3: "ENODEVICE", -4: "EHIP", -5: "ENOMEM"}
+
+
+class HipDecoder:
+    """One decode context on one GPU (== one reference `Decoder` + its thread_local colour-correction state)."""
+
+    def __init__(self, device=0, mode=68):
+        self._lib = load_library()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.cimbar_hip_create(int(device), int(mode), ctypes.byref(self._ctx))
+        if rc != 0:
+            self._ctx = ctypes.c_void_p()
+            raise CimbarHipError(f"cimbar_hip_create(device={device}, mode={mode}) failed: {_ERR.get(rc, rc)} "
+                                 "(a gfx950 GPU is required; there is no CPU fallback)")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.cimbar_hip_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self._lib.cimbar_hip_last_error(self._ctx).decode("utf-8", "replace")
+            raise CimbarHipError(f"{what}: {_ERR.get(int(rc), rc)} {msg}")
+        return rc
+
+    # ------------------------------------------------------------------ host-memory entry points
+    def decode_frame(self, rgb, should_preprocess=False, color_correction=2):
+        """rgb: (1024,1024,3) uint8 numpy array. Returns (good_bytes, chunks (12,625) uint8, mask int)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise CimbarHipError("decode_frame: expected an HxWx3 uint8 image")
+        chunks = np.zeros((modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        mask = ctypes.c_uint32(0)
+        rc = self._lib.cimbar_hip_decode_frame(self._ctx, rgb.ctypes.data, rgb.shape[1], rgb.shape[0], rgb.strides[0],
+                                               int(bool(should_preprocess)), int(color_correction), chunks.ctypes.data,
+                                               ctypes.byref(mask))
+        self._check(rc, "cimbar_hip_decode_frame")
+        return rc, chunks, mask.value
+
+    def decode_batch(self, frames, should_preprocess=False, color_correction=2):
+        """frames: (n,1024,1024,3) uint8 numpy. Returns (total_good_bytes, chunks (n,12,625), masks (n,) uint32)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        if frames.shape[1:] != (modeb.IMG, modeb.IMG, 3):
+            raise CimbarHipError("decode_batch: frames must be (n,1024,1024,3) uint8")
+        chunks = np.zeros((n, modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        masks = np.zeros(n, dtype=np.uint32)
+        rc = self._lib.cimbar_hip_decode_batch(self._ctx, frames.ctypes.data, n, MEM_HOST, int(bool(should_preprocess)),
+                                               int(color_correction), chunks.ctypes.data, masks.ctypes.data, MEM_HOST, None)
+        self._check(rc, "cimbar_hip_decode_batch")
+        return int(rc), chunks, masks
+
+    # ------------------------------------------------------------------ device-memory entry point (torch tensors as raw memory)
+    def decode_batch_device(self, frames_ptr, n, chunks_ptr, masks_ptr, should_preprocess=False, color_correction=2, stream=None):
+        """Enqueue a batch whose input and outputs are device pointers (ints). Asynchronous: caller synchronises `stream`."""
+        rc = self._lib.cimbar_hip_decode_batch(self._ctx, ctypes.c_void_p(frames_ptr), int(n), MEM_DEVICE,
+                                               int(bool(should_preprocess)), int(color_correction), ctypes.c_void_p(chunks_ptr),
+                                               ctypes.c_void_p(masks_ptr), MEM_DEVICE,
+                                               ctypes.c_void_p(stream) if stream else None)
+        self._check(rc, "cimbar_hip_decode_batch(device)")
+        return int(rc)
+
+    # ------------------------------------------------------------------ the reference's operator surface
+    def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):
+        """Decoder::decode_fountain (Decoder.h:171-189): good chunks go to ostream.write(bytes) in chunk order; returns good bytes.
+        Like the reference, a sink whose chunk_size() is not 625 gets nothing written but the byte count is still returned."""
+        good, chunks, mask = self.decode_frame(img, should_preprocess, color_correction)
+        feed = True
+        if hasattr(ostream, "chunk_size") and ostream.chunk_size() != modeb.CHUNK:
+            feed = False
+        if feed:
+            for j in range(modeb.CHUNKS_PER_FRAME):
+                if mask & (1 << j):
+                    ostream.write(chunks[j].tobytes())
+        return good
+
+    # ------------------------------------------------------------------ state / taps / timing
+    def reset_ccm(self):
+        self._check(self._lib.cimbar_hip_reset_ccm(self._ctx), "cimbar_hip_reset_ccm")
+
+    def get_ccm(self):
+        out = (ctypes.c_float * 9)()
+        rc = self._check(self._lib.cimbar_hip_get_ccm(self._ctx, out), "cimbar_hip_get_ccm")
+        return bool(rc), np.array(list(out), dtype=np.float32).reshape(3, 3)
+
+    def tap(self, what, n):
+        shapes = {
+            TAP_BITPLANE: ((n, modeb.IMG * modeb.IMG // 8), np.uint8), TAP_SYMBOLS: ((n, modeb.NCELLS), np.uint8),
+            TAP_COLORS: ((n, modeb.NCELLS), np.uint8), TAP_DRIFT: ((n, modeb.NCELLS, 2), np.int8),
+            TAP_RS_OK: ((n, 60), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32),
+        }
+        shape, dt = shapes[what]
+        out = np.zeros(shape, dtype=dt)
+        self._check(self._lib.cimbar_hip_tap(self._ctx, what, out.ctypes.data, out.nbytes), "cimbar_hip_tap")
+        return out
+
+    def enable_timing(self, on=True):
+        self._lib.cimbar_hip_enable_timing(self._ctx, int(bool(on)))
+
+    def stage_times(self):
+        names = (ctypes.c_char_p * 16)()
+        ms = (ctypes.c_float * 16)()
+        k = self._check(self._lib.cimbar_hip_stage_times(self._ctx, names, ms, 16), "cimbar_hip_stage_times")
+        return {names[i].decode(): float(ms[i]) for i in range(k)}

@@ -1,0 +1,53 @@
+"""Frame-parallel sharding across the GPUs of one node + gather of the decoded chunks to a single sink on rank 0.
+
+Frames are independent units (reference TODO.md:15), so rank r decodes the contiguous slab [r*n/W, (r+1)*n/W) with no
+data-path collective; the only exchange is one fixed-size gather per batch (n_r * (12*625 + 4) bytes per rank), which is
+what the reference's own worker pool does with postMessage (web/recv-worker.js:47-64 -> web/recv.js:36). With the `nccl`
+backend that gather is RCCL over xGMI; the CPU tests run the same code on `gloo`.
+"""
+import torch
+import torch.distributed as dist
+
+from . import modeb
+
+
+def shard_range(n_frames, rank, world):
+    """Contiguous slab of frames owned by `rank` (the last ranks get the shorter slabs when n % world != 0)."""
+    per = (n_frames + world - 1) // world
+    lo = min(rank * per, n_frames)
+    hi = min(lo + per, n_frames)
+    return lo, hi, per
+
+
+def gather_chunks(chunks, masks, dst=0, group=None):
+    """chunks: (n_r, 7500) uint8, masks: (n_r,) int32 on every rank (same n_r everywhere). On `dst` returns
+    (chunks (W*n_r, 7500), masks (W*n_r,)) in rank order == frame order; elsewhere (None, None)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return chunks, masks
+    if rank == dst:
+        cl = [torch.empty_like(chunks) for _ in range(world)]
+        ml = [torch.empty_like(masks) for _ in range(world)]
+        dist.gather(chunks, cl, dst=dst, group=group)
+        dist.gather(masks, ml, dst=dst, group=group)
+        return torch.cat(cl, 0), torch.cat(ml, 0)
+    dist.gather(chunks, None, dst=dst, group=group)
+    dist.gather(masks, None, dst=dst, group=group)
+    return None, None
+
+
+def feed_sink(sink_decode_frame, chunks, masks):
+    """Rank-0 side: hand every delivered chunk to fountain_decoder_sink::decode_frame (fountain_decoder_sink.h:133-166) in
+    frame order then chunk order -- exactly the order a single-threaded reference decoder would have produced.
+    Returns the list of non-zero results (completed file ids / error codes)."""
+    out = []
+    c = chunks.cpu().numpy().reshape(-1, modeb.CHUNKS_PER_FRAME, modeb.CHUNK)
+    m = masks.cpu().numpy()
+    for f in range(c.shape[0]):
+        for j in range(modeb.CHUNKS_PER_FRAME):
+            if int(m[f]) & (1 << j):
+                r = sink_decode_frame(c[f, j])
+                if r != 0:
+                    out.append(r)
+    return out

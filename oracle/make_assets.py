@@ -1,0 +1,33 @@
+"""Regenerates fixtures that need the REFERENCE build (oracle/_ref/libcimbar_ref.so, i.e. /root/reference at build time):
+
+  libcimbar_amd/data/modeb_template.npz   background + anchors + guides of an empty mode-B frame (CimbWriter.cpp:39-77),
+                                          stored sparse (flat byte index, value) -- input of libcimbar_amd/framegen.py
+  tests/golden/*.npz                      see tests/golden/README.md
+
+Run here (in the build container); the outputs are committed so that nothing at test/bench time needs /root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyref import P, ref_lib  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    L = ref_lib()
+    if L is None:
+        raise SystemExit("oracle/_ref/libcimbar_ref.so missing: run `make -C oracle ref` first")
+    t = np.zeros(1024 * 1024 * 3, np.uint8)
+    L.ref_template_frame(P(t))
+    idx = np.nonzero(t)[0].astype(np.uint32)
+    os.makedirs(os.path.join(ROOT, "libcimbar_amd", "data"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "libcimbar_amd", "data", "modeb_template.npz"), idx=idx, val=t[idx])
+    print("template: %d non-zero bytes" % idx.size)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Shared input manufacture for the parity tests (seeded, deterministic)."""
+import numpy as np
+import torch
+
+from libcimbar_amd import framegen, modeb
+
+
+def clean_frames(synth, n, seed=1234, **kw):
+    payload = framegen.synth_payload(n, seed=seed, **kw)
+    frames = synth.frames_from_payload(payload).numpy()
+    return payload.numpy(), frames
+
+
+def tile_error_frames(synth, n, seed=1234, n_errors=99):
+    payload = framegen.synth_payload(n, seed=seed)
+    tiles = synth.cell_tiles(payload)
+    bad = framegen.inject_cell_errors(tiles, n_errors=n_errors, seed=5678)
+    return payload.numpy(), synth.render(bad).numpy()
+
+
+def add_noise(frame, sigma, seed):
+    g = np.random.default_rng(seed)
+    return np.clip(frame.astype(np.int16) + g.normal(0, sigma, frame.shape).astype(np.int16), 0, 255).astype(np.uint8)
+
+
+def shift(frame, dy, dx):
+    return np.roll(frame, (dy, dx), (0, 1))
+
+
+def rescale(frame, grow):
+    """grow the image by `grow` pixels and crop the centre: cells drift progressively away from the grid."""
+    from PIL import Image
+    n = modeb.IMG + grow
+    im = Image.fromarray(frame).resize((n, n), Image.BILINEAR)
+    o = grow // 2
+    return np.array(im.crop((o, o, o + modeb.IMG, o + modeb.IMG)))
+
+
+def blank_region(frame, y0, y1, x0, x1, value=0):
+    out = frame.copy()
+    out[y0:y1, x0:x1] = value
+    return out
+
+
+def distorted_set(synth, seed=77):
+    """A labelled list of frames covering: clean, pixel noise, rigid shifts, progressive drift, partial wipe-outs."""
+    payload, frames = clean_frames(synth, 4, seed=seed)
+    f = frames
+    out = [
+        ("clean", f[0]),
+        ("noise40", add_noise(f[1], 40, 1)),
+        ("noise120", add_noise(f[2], 120, 2)),
+        ("shift+2+1", shift(f[0], 2, 1)),
+        ("shift-3+4", shift(f[1], -3, 4)),
+        ("shift+1+0", shift(f[2], 1, 0)),
+        ("rescale+6", rescale(f[3], 6)),
+        ("rescale+10", rescale(f[0], 10)),
+        ("wipe_band", blank_region(f[1], 300, 420, 0, 1024)),
+        ("wipe_half", blank_region(f[2], 0, 1024, 0, 560, value=255)),
+        ("wipe_corner", blank_region(f[3], 60, 500, 60, 700)),
+        ("noise200", add_noise(f[3], 200, 3)),
+    ]
+    return out
