@@ -68,7 +68,7 @@ def cpu_baseline(frames_host, budget_s=15.0):
     decode_one(frames_host[0], st)
     decode_one(frames_host[0], st)
     per_frame = (time.perf_counter() - t0) / 2
-    total = int(max(threads, min(len(frames_host), budget_s / per_frame * threads)))
+    total = int(max(threads, budget_s / per_frame * threads))
     done = [0] * threads
 
     def worker(tid):

@@ -1118,18 +1118,45 @@ void host_cell_positions(std::vector<ushort2>& xy)
 	for (int i = 0; i < TOP_CELLS; ++i, ++n) xy[n] = make_ushort2((i % TOP_W) * PITCH + PITCH * MARKER + OFFSET, (i / TOP_W) * PITCH + (DIM - MARKER) * PITCH + OFFSET);
 }
 
-// AdjacentCellFinder.cpp:16-105 expressed on (band, row, col) instead of position look-ups
-struct Grid {
-	static int row_of(int i) { return i < TOP_CELLS ? i / TOP_W : (i < TOP_CELLS + MID_CELLS ? MARKER + (i - TOP_CELLS) / DIM : DIM - MARKER + (i - TOP_CELLS - MID_CELLS) / TOP_W); }
-	static int col_of(int i) { return i < TOP_CELLS ? MARKER + i % TOP_W : (i < TOP_CELLS + MID_CELLS ? (i - TOP_CELLS) % DIM : MARKER + (i - TOP_CELLS - MID_CELLS) % TOP_W); }
-	static int index_of(int row, int col)
+// AdjacentCellFinder.cpp:16-105, literally (position look-ups included): the index arithmetic there has band-edge quirks
+// (e.g. cells 494..499 have no "bottom", 11900..11905 no "top") that the flood order depends on.
+struct AdjFinder {
+	const std::vector<ushort2>& pos;
+	static int in_row_with_margin(int index) { return (index < TOP_CELLS) ? 1 : (index < TOP_CELLS + MID_CELLS ? 0 : 1); }
+	int right(int index) const
 	{
-		if (row < 0 || row >= DIM || col < 0 || col >= DIM) return -1;
-		bool margin = row < MARKER || row >= DIM - MARKER;
-		if (margin && (col < MARKER || col >= DIM - MARKER)) return -1;
-		if (row < MARKER) return row * TOP_W + (col - MARKER);
-		if (row < DIM - MARKER) return TOP_CELLS + (row - MARKER) * DIM + col;
-		return TOP_CELLS + MID_CELLS + (row - (DIM - MARKER)) * TOP_W + (col - MARKER);
+		if (index < 0 || index >= NCELLS - 1) return -1;
+		int next = index + 1;
+		if (pos[next].x < pos[index].x) return -1;
+		return next;
+	}
+	int left(int index) const
+	{
+		int next = index - 1;
+		if (next < 0) return -1;
+		if (pos[next].x > pos[index].x) return -1;
+		return next;
+	}
+	int bottom(int index) const
+	{
+		if (index < 0 || index >= NCELLS) return -1;
+		int inc = DIM;
+		if (in_row_with_margin(index)) inc -= MARKER;
+		int next = index + inc;
+		if (in_row_with_margin(next)) next -= MARKER;
+		if (next < 0 || next >= NCELLS) return -1;
+		if (pos[next].x != pos[index].x) return -1;
+		return next;
+	}
+	int top(int index) const
+	{
+		int inc = DIM;
+		if (in_row_with_margin(index)) inc -= MARKER;
+		int next = index - inc;
+		if (in_row_with_margin(next)) next += MARKER;
+		if (next < 0) return -1;
+		if (pos[next].x != pos[index].x) return -1;
+		return next;
 	}
 };
 
@@ -1145,12 +1172,12 @@ int build_tables(cimbar_hip_ctx* ctx)
 		for (int chunk = 0; chunk < RS_BLOCK; ++chunk)
 			for (int i = chunk; i < part_size; i += RS_BLOCK) sc.push_back((uint16_t)(i + part));
 	std::vector<int16_t> adj((size_t)NCELLS * 4);
+	AdjFinder finder{xy};
 	for (int i = 0; i < NCELLS; ++i) {
-		int r = Grid::row_of(i), c = Grid::col_of(i);
-		adj[(size_t)i * 4 + 0] = (int16_t)Grid::index_of(r, c + 1);
-		adj[(size_t)i * 4 + 1] = (int16_t)Grid::index_of(r, c - 1);
-		adj[(size_t)i * 4 + 2] = (int16_t)Grid::index_of(r + 1, c);
-		adj[(size_t)i * 4 + 3] = (int16_t)Grid::index_of(r - 1, c);
+		adj[(size_t)i * 4 + 0] = (int16_t)finder.right(i);
+		adj[(size_t)i * 4 + 1] = (int16_t)finder.left(i);
+		adj[(size_t)i * 4 + 2] = (int16_t)finder.bottom(i);
+		adj[(size_t)i * 4 + 3] = (int16_t)finder.top(i);
 	}
 	// GF(2^8) tables, libcorrect field.h:26-62 with primitive polynomial 0x187 (correct.h:159-160)
 	uint8_t gexp[512], glog[256];
