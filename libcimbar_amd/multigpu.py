@@ -37,10 +37,12 @@ def gather_chunks(chunks, masks, dst=0, group=None):
     return None, None
 
 
-def feed_sink(sink_decode_frame, chunks, masks):
+def feed_sink(sink_decode_frame, chunks, masks, on_complete=None):
     """Rank-0 side: hand every delivered chunk to fountain_decoder_sink::decode_frame (fountain_decoder_sink.h:133-166) in
     frame order then chunk order -- exactly the order a single-threaded reference decoder would have produced.
-    Returns the list of non-zero results (completed file ids / error codes)."""
+    A positive return means "file <id> is complete": `on_complete(id)` runs at once (that is where the caller recovers /
+    stores the file, which also marks it done so that later chunks of the same stream are ignored, as in
+    fountain_decoder_sink.h:77-96,146-148). Returns the list of non-zero results."""
     out = []
     c = chunks.cpu().numpy().reshape(-1, modeb.CHUNKS_PER_FRAME, modeb.CHUNK)
     m = masks.cpu().numpy()
@@ -50,4 +52,6 @@ def feed_sink(sink_decode_frame, chunks, masks):
                 r = sink_decode_frame(c[f, j])
                 if r != 0:
                     out.append(r)
+                if r > 0 and on_complete is not None:
+                    on_complete(r)
     return out

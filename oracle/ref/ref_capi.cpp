@@ -54,24 +54,43 @@ struct ExposedReader : CimbReader
 	const std::vector<char>& bitplane() const { return _grayscale.buffer(); }
 };
 
+// Sits where do_decode expects its STREAM (between reed_solomon_stream and the reference's aligned_stream) and only
+// counts RS blocks, so that a chunk delivered by aligned_stream can be attributed to its slot (block group / 5).
+struct block_counting_tee
+{
+	aligned_stream<chunk_collector>& inner;
+	unsigned blocks = 0;
+	explicit block_counting_tee(aligned_stream<chunk_collector>& a) : inner(a) {}
+	bool good() const { return inner.good(); }
+	long tellp() const { return inner.tellp(); }
+	block_counting_tee& write(const char* d, unsigned n) { blocks += 1; inner.write(d, n); return *this; }
+};
+inline block_counting_tee& operator<<(block_counting_tee& s, const ReedSolomon::BadChunk& chunk)
+{
+	s.blocks += 1;
+	s.inner.mark_bad_chunk(chunk.size);   // == operator<<(aligned_stream&, BadChunk), reed_solomon_stream.h:109-114
+	return s;
+}
+
 struct RefDecoder : Decoder
 {
 	using Decoder::Decoder;
 
-	// Decoder::decode_fountain (Decoder.h:171-189) with the chunk outcome recorded beside update_metadata
-	unsigned decode_fountain_masked(const cv::Mat& img, chunk_collector& out, uint32_t& mask, bool pre, int cc)
+	// Decoder::decode_fountain (Decoder.h:171-189), same objects (CimbReader, aligned_stream bound to update_metadata,
+	// do_decode); the tee records which 5-block group each delivered chunk came from.
+	unsigned decode_fountain_masked(const cv::Mat& img, chunk_collector& out, std::vector<unsigned>& slots, bool pre, int cc)
 	{
 		CimbReader reader(img, _decoder, cimbar::Config::color_mode(), pre, cc);
 		unsigned chunk_size = cimbar::Config::fountain_chunk_size();
-		unsigned idx = 0;
-		mask = 0;
+		block_counting_tee* teep = nullptr;
 		auto on_flush = [&](char* buf, size_t len) {
 			reader.update_metadata(buf, len, chunk_size);
-			if (buf != nullptr && len > 0) mask |= (1u << idx);
-			++idx;
+			if (buf != nullptr && len > 0) slots.push_back((teep->blocks - 1) / 5);
 		};
 		aligned_stream<chunk_collector> aligner(out, out.chunk_size(), 0, on_flush);
-		return do_decode(reader, aligner);
+		block_counting_tee tee(aligner);
+		teep = &tee;
+		return do_decode(reader, tee);
 	}
 };
 
@@ -189,17 +208,17 @@ int ref_decode_fountain(const uint8_t* rgb, unsigned w, unsigned h, int preproce
 
 	RefDecoder dec;
 	chunk_collector col(cs);
-	uint32_t mask = 0;
-	unsigned res = dec.decode_fountain_masked(img, col, mask, preprocess != 0, color_correction);
+	std::vector<unsigned> slots;
+	unsigned res = dec.decode_fountain_masked(img, col, slots, preprocess != 0, color_correction);
 
 	std::memset(chunks, 0, (size_t)per_frame * cs);
-	size_t off = 0;
-	for (unsigned j = 0; j < per_frame; ++j)
-		if (mask & (1u << j))
-		{
-			std::memcpy(chunks + (size_t)j * cs, col.bytes.data() + off, cs);
-			off += cs;
-		}
+	uint32_t mask = 0;
+	for (size_t k = 0; k < slots.size(); ++k)
+	{
+		if (slots[k] >= per_frame) continue;
+		std::memcpy(chunks + (size_t)slots[k] * cs, col.bytes.data() + k * cs, cs);
+		mask |= 1u << slots[k];
+	}
 	if (good_mask) *good_mask = mask;
 	return (int)res;
 }

@@ -1,0 +1,48 @@
+"""The C-ABI library loads and exports every symbol include/cimbar_hip.h declares (no compute: runs without a GPU)."""
+import os
+import re
+
+import pytest
+
+from libcimbar_amd import decoder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "cimbar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cimbar_hip_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(decoder.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(decoder.LIB_PATH):
+        pytest.fail("libcimbar_hip.so not built: run `python -m libcimbar_amd.build` (or __graft_entry__.build())")
+    lib = decoder.load_library()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.cimbar_hip_bufsize() == 7500
+
+
+def test_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(decoder.CimbarHipError):
+        decoder.HipDecoder(0)
+
+
+def test_product_never_touches_the_oracle():
+    # the oracle is test infrastructure: nothing under libcimbar_amd/ or include/ may import, include, link or dlopen it
+    pats = [r"^\s*(import|from)\s+oracle\b", r"#\s*include\s*[<\"][^>\"]*oracle", r"libcimbar_oracle", r"libcimbar_ref", r"\bpyref\b"]
+    for base in ("libcimbar_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                    text = open(os.path.join(dirpath, fn), errors="replace").read()
+                    for pat in pats:
+                        assert not re.search(pat, text, flags=re.M), (fn, pat)

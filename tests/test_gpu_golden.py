@@ -1,0 +1,39 @@
+"""GPU: the HIP path against the committed fixtures generated from the reference build (tests/golden)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from libcimbar_amd import decoder as D
+from tests import frames as F
+from tests.test_oracle_golden import _inputs
+
+pytestmark = pytest.mark.gpu
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "modeb_golden.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def golden_inputs(synth):
+    return _inputs(synth)
+
+
+@pytest.mark.parametrize("case", GOLDEN["cases"], ids=lambda c: f"{c['name']}-pre{c['preprocess']}-cc{c['color_correction']}")
+def test_hip_matches_reference_fixture(case, golden_inputs, hip_decoder):
+    frame = np.ascontiguousarray(golden_inputs[case["name"]])
+    if sha(frame) != case["input_sha256"]:
+        pytest.skip("input regeneration differs on this host (PIL/numpy version) -- fixture not applicable")
+    hip_decoder.reset_ccm()
+    good, chunks, mask = hip_decoder.decode_frame(frame, bool(case["preprocess"]), case["color_correction"])
+    assert (good, mask) == (case["ret"], case["mask"])
+    assert sha(chunks) == case["chunks_sha256"]
+    assert sha(hip_decoder.tap(D.TAP_BITPLANE, 1)[0]) == case["bitplane_sha256"]
+    active, m = hip_decoder.get_ccm()
+    assert int(active) == case["ccm_active"]
+    if active:
+        assert [int(x) for x in m.reshape(-1).view(np.uint32)] == case["ccm_bits"]

@@ -1,0 +1,104 @@
+"""Differential tests: oracle/cimbar_oracle.c against the reference's own code (oracle/_ref). Skipped where _ref is absent."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from libcimbar_amd import modeb
+from oracle import pyref
+from oracle.pyref import P
+from tests import frames as F
+
+
+def test_tile_hashes_and_tiles(ref, synth):
+    h = (ctypes.c_uint64 * 16)()
+    assert ref.ref_tile_hashes(h) == 16
+    assert list(h) == [int(x) for x in modeb.TILE_HASHES]
+    for c in range(4):
+        for s in range(16):
+            t = np.zeros(192, np.uint8)
+            assert ref.ref_tile_rgb(s, c, 1, P(t)) == 0
+            assert (t.reshape(8, 8, 3) == synth.tiles[c * 16 + s].numpy()).all()
+
+
+def test_interleave_and_rs_encode(ref, oracle):
+    a = np.zeros(12400, np.uint32)
+    b = np.zeros(12400, np.uint32)
+    ref.ref_interleave_reverse(12400, 155, 2, P(a))
+    oracle.co_interleave_reverse(P(b))
+    assert (a == b).all()
+    g = np.random.default_rng(5)
+    for _ in range(50):
+        msg = g.integers(0, 256, 125, dtype=np.uint8)
+        e1, e2 = np.zeros(155, np.uint8), np.zeros(155, np.uint8)
+        ref.ref_rs_encode(P(msg), 125, 30, P(e1))
+        oracle.co_rs_encode(P(msg), 125, 30, P(e2))
+        assert (e1 == e2).all()
+
+
+def test_rs_decode_fuzz_including_failure_regime(ref, oracle):
+    g = np.random.default_rng(6)
+    succ = 0
+    for t in range(1500):
+        msg = g.integers(0, 256, 125, dtype=np.uint8)
+        enc = np.zeros(155, np.uint8)
+        ref.ref_rs_encode(P(msg), 125, 30, P(enc))
+        ne = int(g.integers(0, 30))
+        pos = g.choice(155, ne, replace=False)
+        bad = enc.copy()
+        bad[pos] ^= g.integers(1, 256, ne, dtype=np.uint8)
+        o1, o2 = np.zeros(125, np.uint8), np.zeros(125, np.uint8)
+        r1 = ref.ref_rs_decode(P(bad), 155, 30, P(o1))
+        r2 = oracle.co_rs_decode(P(bad), 155, 30, P(o2))
+        assert r1 == r2, (t, ne)
+        if r1 > 0:
+            assert (o1 == o2).all(), (t, ne)
+            succ += 1
+    assert 700 < succ < 1000
+
+
+def test_color_classifier_fuzz(ref, oracle):
+    ref.ref_reset_ccm()
+    g = np.random.default_rng(8)
+    for _ in range(3000):
+        r, gg, b = (float(x) for x in g.integers(0, 256, 3))
+        assert ref.ref_best_color(r, gg, b) == oracle.co_best_color(r, gg, b, None)
+
+
+@pytest.mark.parametrize("pre", [0, 1])
+def test_stages_on_distorted_frames(ref, oracle, synth, pre):
+    for name, frame in F.distorted_set(synth, seed=123):
+        frame = np.ascontiguousarray(frame)
+        b1, v1 = np.zeros(131072, np.uint8), np.zeros(4 * 12400, np.int32)
+        assert ref.ref_symbol_pass(P(frame), 1024, 1024, pre, P(b1), P(v1)) == 12400
+        b2, v2 = np.zeros(131072, np.uint8), np.zeros(4 * 12400, np.int32)
+        oracle.co_threshold_bitplane(P(frame), 1024, 1024, pre, P(b2))
+        assert (b1 == b2).all(), name
+        assert oracle.co_symbol_pass(P(b2), P(v2), None) == 12400
+        assert (v1 == v2).all(), name
+
+
+@pytest.mark.parametrize("cc", [0, 1, 2])
+def test_whole_decode_with_ccm_carry(ref, synth, cc):
+    # one reference thread decoding a sequence == the oracle carrying its co_ccm through the same sequence
+    items = F.distorted_set(synth, seed=321)
+    ref.ref_reset_ccm()
+    ccm = pyref.CoCcm()
+    for name, frame in items:
+        r1, c1, m1 = pyref.ref_decode(frame, 0, cc, reset_ccm=0)
+        r2, c2, m2, ccm = pyref.oracle_decode(frame, 0, cc, ccm)
+        assert (r1, m1) == (r2, m2), name
+        assert (c1 == c2).all(), name
+        rc = (ctypes.c_float * 9)()
+        active = ref.ref_get_ccm(rc)
+        assert active == ccm.active, name
+        if active:
+            assert np.array(list(rc), np.float32).tobytes() == np.array(list(ccm.m), np.float32).tobytes(), name
+
+
+def test_escrow_writer_entry_point(ref, synth):
+    # the literal public API (Decoder::decode_fountain into an escrow_buffer_writer, cimbar_recv_js.cpp:160-188)
+    payload, frames = F.clean_frames(synth, 1, seed=2)
+    buf = np.zeros(7500, np.uint8)
+    assert ref.ref_decode_fountain_escrow(P(np.ascontiguousarray(frames[0])), 1024, 1024, 0, 2, 1, P(buf)) == 7500
+    assert (buf == payload[0]).all()
