@@ -64,13 +64,20 @@ struct Tables {
 };
 
 // ------------------------------------------------------------------------------------------------ K1 threshold+pack
-// CimbReader.cpp:30-46 preprocessSymbolGrid + bitmatrix.h:14-46. One wavefront owns a full-width strip of ROWS pixel
-// rows: lane l holds columns [16l, 16l+16) and the wave walks down the strip, so every RGB byte is loaded once
-// (3 x 16 B per lane per row), the 5x5|7x7 box sums live in registers and no LDS / barrier is needed.
+// CimbReader.cpp:30-46 preprocessSymbolGrid + bitmatrix.h:14-46, fused with the colour pass's pixel reads.
+// One wavefront owns a full-width strip of pixel rows: lane l holds columns [16l, 16l+16) and the wave walks down the
+// strip, so every RGB byte is loaded from HBM exactly once (3 x 16 B per lane per row, next row prefetched while the
+// current one is processed); the 5x5|7x7 box sums live in registers.
 //   gray  = (R*9798 + G*19235 + B*3735 + 2^14) >> 15                                 [assumed-OpenCV]
 //   bit   = gray > round(box_sum / n)   <=>   n*gray > box_sum + n/2   (n = 25 | 49), BORDER_REPLICATE
-// Output layout: plane[frame][row][32 words], pixel x -> word x/32, bit 31-(x%32).
-constexpr int K1_ROWS = 32;
+// Output 1: plane[frame][row][32 words], pixel x -> word x/32, bit 31-(x%32).
+// Output 2: cellmean[frame][112*112] = r | g<<8 | b<<16, the inner-6x6 mean (Cell.h:30-62: uint16 sums / 36) of every
+//           cell at its UNDRIFTED grid position -- what read_color / init_ccm sample when no drift is in play
+//           (CimbReader.cpp:133-137,216-217). Strips are aligned to the cell grid (16 strips x 7 cell rows), so a cell's
+//           six inner rows always belong to one wave: per-byte column sums accumulate in registers over those rows and
+//           are regrouped into cells through a 6 KiB LDS transpose once per cell row.
+constexpr int K1_STRIPS = 16, K1_CELLROWS = DIM / K1_STRIPS;   // 7 cell rows = 63 pixel rows per strip (+8 px margin at both ends)
+constexpr int GRID_CELLS = DIM * DIM;
 
 __device__ __forceinline__ void load_row48(const uint8_t* __restrict__ row, int lane, uint32_t d[12])
 {
@@ -91,137 +98,208 @@ __device__ __forceinline__ void gray16(const uint32_t d[12], uint32_t g[16])
 		g[p] = (byte_of(d, 3 * p) * 9798u + byte_of(d, 3 * p + 1) * 19235u + byte_of(d, 3 * p + 2) * 3735u + 16384u) >> 15;
 }
 
-// neighbours' edge pixels: lo = pixels [-RAD..-1] (from lane-1), hi = pixels [16..16+RAD-1] (from lane+1), with the
-// image border handled by the caller-supplied policy (replicate for the box filter, reflect101 for the sharpen taps)
-template <int RAD>
-__device__ __forceinline__ void halo(const uint32_t g[16], int lane, bool reflect, uint32_t ext[16 + 2 * RAD])
+// 16 gray pixels straight from the 12 raw dwords with v_dot4_u32_u8: pixel p starts at byte 3p; the dot product's fourth
+// coefficient is 0, so the dword may carry the next pixel's first byte. Coefficients split hi/lo byte:
+// 9798 = 38*256+70, 19235 = 75*256+35, 3735 = 14*256+151.
+__device__ __forceinline__ void gray16_dot(const uint32_t d[12], uint32_t g[16])
 {
-	uint32_t tail = 0, head = 0;
+	constexpr uint32_t LO = 70u | (35u << 8) | (151u << 16), HI = 38u | (75u << 8) | (14u << 16);
 #pragma unroll
-	for (int k = 0; k < RAD; ++k) { tail |= g[16 - RAD + k] << (8 * k); head |= g[k] << (8 * k); }
-	uint32_t from_left = __shfl_up(tail, 1), from_right = __shfl_down(head, 1);
-#pragma unroll
-	for (int p = 0; p < 16; ++p) ext[RAD + p] = g[p];
-#pragma unroll
-	for (int k = 0; k < RAD; ++k) {
-		uint32_t l = (from_left >> (8 * k)) & 0xFFu;      // pixel (-RAD + k)
-		uint32_t r = (from_right >> (8 * k)) & 0xFFu;     // pixel (16 + k)
-		if (lane == 0) l = reflect ? g[RAD - k] : g[0];
-		if (lane == 63) r = reflect ? g[14 - k] : g[15];
-		ext[k] = l;
-		ext[16 + RAD + k] = r;
+	for (int p = 0; p < 16; ++p) {
+		const int w = (3 * p) >> 2, sh = (3 * p) & 3;
+		uint32_t v;
+		if (sh == 0) v = d[w];
+		else if (w == 11) v = d[11] >> (8 * sh);
+		else v = __builtin_amdgcn_alignbyte(d[w + 1], d[w], sh);
+		uint32_t lo = __builtin_amdgcn_udot4(v, LO, 16384u, false);
+		uint32_t hi = __builtin_amdgcn_udot4(v, HI, 0u, false);
+		g[p] = ((hi << 8) + lo) >> 15;
 	}
 }
 
-// horizontal (2*RAD+1)-sums of the 16 pixels, packed two u16 per register: out[q] = h[2q] | h[2q+1] << 16
-template <int RAD>
-__device__ __forceinline__ void hsum16(const uint32_t ext[16 + 2 * RAD], uint32_t out[8])
-{
-	uint32_t s = 0;
-#pragma unroll
-	for (int k = 0; k < 2 * RAD + 1; ++k) s += ext[k];
-	uint32_t h[16];
-	h[0] = s;
-#pragma unroll
-	for (int p = 1; p < 16; ++p) { s += ext[p + 2 * RAD] - ext[p - 1]; h[p] = s; }
-#pragma unroll
-	for (int q = 0; q < 8; ++q) out[q] = h[2 * q] | (h[2 * q + 1] << 16);
-}
+// lane l <- lane l-1 (lane 0 keeps `edge`), lane l <- lane l+1 (lane 63 keeps `edge`): DPP wave shifts, one VALU op each
+__device__ __forceinline__ uint32_t from_left_lane(uint32_t v, uint32_t edge) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_right_lane(uint32_t v, uint32_t edge) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }
 
-__device__ __forceinline__ void pack_gray(const uint32_t g[16], uint32_t out[4])
-{
-#pragma unroll
-	for (int q = 0; q < 4; ++q) out[q] = g[4 * q] | (g[4 * q + 1] << 8) | (g[4 * q + 2] << 16) | (g[4 * q + 3] << 24);
-}
+__device__ __forceinline__ const uint8_t* row_ptr(const uint8_t* __restrict__ frame, int r) { return frame + (size_t)r * (IMG * 3); }
 
-// gray row `r` (already clamped/reflected by the caller) for this lane
-__device__ __forceinline__ void gray_row(const uint8_t* __restrict__ frame, int r, int lane, uint32_t g[16])
+// CimbReader.cpp:17-27 sharpen: filter2D with [0 -1 0; -1 4.5 -1; 0 -1 0], BORDER_REFLECT_101, saturate(round-half-even).
+// dc = raw bytes of row r (for the colour sums), s = sharpened gray of row r.
+__device__ __forceinline__ void sharp_row(const uint8_t* __restrict__ frame, int r, int lane, uint32_t dc[12], uint32_t s[16])
 {
-	uint32_t d[12];
-	load_row48(frame + (size_t)r * (IMG * 3), lane, d);
-	gray16(d, g);
-}
-
-// CimbReader.cpp:17-27 sharpen: filter2D with [0 -1 0; -1 4.5 -1; 0 -1 0], BORDER_REFLECT_101, saturate(round-half-even)
-__device__ __forceinline__ void sharp_row(const uint8_t* __restrict__ frame, int r, int lane, uint32_t s[16])
-{
-	uint32_t gn[16], gc[16], gs[16];
+	uint32_t dn[12], ds[12], gn[16], gc[16], gs[16];
 	int rn = r - 1 < 0 ? 1 : r - 1, rs = r + 1 >= IMG ? IMG - 2 : r + 1;
-	gray_row(frame, rn, lane, gn);
-	gray_row(frame, r, lane, gc);
-	gray_row(frame, rs, lane, gs);
-	uint32_t ext[18];
-	halo<1>(gc, lane, true, ext);
+	load_row48(row_ptr(frame, rn), lane, dn);
+	load_row48(row_ptr(frame, r), lane, dc);
+	load_row48(row_ptr(frame, rs), lane, ds);
+	gray16_dot(dn, gn); gray16_dot(dc, gc); gray16_dot(ds, gs);
+	// west / east neighbours with BORDER_REFLECT_101: pixel -1 -> pixel 1, pixel 16 of the last lane -> pixel 14
+	const uint32_t west0 = from_left_lane(gc[15], gc[1]), east15 = from_right_lane(gc[0], gc[14]);
 #pragma unroll
 	for (int p = 0; p < 16; ++p) {
-		int t = 9 * (int)gc[p] - 2 * (int)(gn[p] + gs[p] + ext[p] + ext[p + 2]);   // = 2 * (4.5c - n - s - w - e), exact
+		const uint32_t w = p == 0 ? west0 : gc[p - 1], e = p == 15 ? east15 : gc[p + 1];
+		int t = 9 * (int)gc[p] - 2 * (int)(gn[p] + gs[p] + w + e);   // = 2 * (4.5c - n - s - w - e), exact
 		int q = t >> 1;
-		if (t & 1) q += (q & 1);                                                   // x.5 -> nearest even
+		if (t & 1) q += (q & 1);                                     // x.5 -> nearest even
 		s[p] = (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
 	}
 }
 
-template <int RAD, bool PRE>
-__global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane)
+// One row of the streaming box-threshold. All per-pixel quantities travel as u16 pairs (pixel i | pixel i+8 << 16), i < 8,
+// so a horizontal neighbour is simply the next register and plain 32-bit adds never carry between the halves.
+//   ring : the last RING gray rows (RING = 2*RAD+2, even, so that the A/B prefetch buffers keep static roles)
+//   C    : per-column sums of the newest 2*RAD+1 rows
+// emit: row (y - RAD) has its full window -> 16 result bits for this lane.
+template <int RAD, int SLOT>
+__device__ __forceinline__ uint32_t box_row(uint32_t (&ring)[2 * RAD + 2][8], uint32_t (&C)[8], const uint32_t g[16], bool emit)
 {
-	constexpr int N = (2 * RAD + 1) * (2 * RAD + 1);
+	constexpr int RING = 2 * RAD + 2, R = 2 * RAD + 1, N = R * R;
+	constexpr int OLD = (SLOT + 1) % RING;            // row y - (2*RAD+1), leaving the window
+	constexpr int CTR = (SLOT + RING - RAD) % RING;   // row y - RAD, the one being emitted
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint32_t G = g[i] | (g[i + 8] << 16);
+		C[i] += G - ring[OLD][i];
+		ring[SLOT][i] = G;
+	}
+	if (!emit) return 0;
+
+	// X[k] = pair register k - RAD, k = 0 .. 8 + 2*RAD - 1: (pixel i, pixel i+8) for i = -RAD .. 7+RAD
+	uint32_t X[8 + 2 * RAD];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) X[RAD + i] = C[i];
+#pragma unroll
+	for (int k = 1; k <= RAD; ++k) {
+		// pixel -k comes from the left lane's pixel 16-k (hi half of its C[8-k]); BORDER_REPLICATE -> own pixel 0 on lane 0
+		const uint32_t left = from_left_lane(C[8 - k] >> 16, C[0] & 0xFFFFu);
+		X[RAD - k] = left | (C[8 - k] << 16);                       // (pixel -k, pixel 8-k)
+		// pixel 15+k comes from the right lane's pixel k-1 (lo half of its C[k-1]); replicate -> own pixel 15 on lane 63
+		const uint32_t right = from_right_lane(C[k - 1] & 0xFFFFu, C[7] >> 16);
+		X[RAD + 7 + k] = (C[k - 1] >> 16) | (right << 16);          // (pixel 7+k, pixel 15+k)
+	}
+	uint32_t S = 0;
+#pragma unroll
+	for (int k = 0; k < R; ++k) S += X[k];
+	constexpr uint32_t K = (0x8000u - (uint32_t)(N / 2) - 1u) * 0x00010001u;
+	uint32_t M = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		if (i > 0) S += X[i + 2 * RAD] - X[i - 1];
+		// N*g > S + N/2  <=>  bit 15 of (N*g + 0x8000 - N/2 - 1 - S), per half; no field under/overflows (|.| <= 12495)
+		const uint32_t r = __umul24(ring[CTR][i], (uint32_t)N) + K - S;
+		M |= (r & 0x80008000u) >> i;
+	}
+	return (M & 0xFF00u) | (M >> 24);   // bit 15-p = pixel p
+}
+
+template <int RAD, bool PRE>
+#ifndef K1_WAVES
+#define K1_WAVES 3
+#endif
+__global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
+                                                                uint32_t* __restrict__ cellmean)
+{
+	constexpr int RING = 2 * RAD + 2;
+	__shared__ __attribute__((aligned(16))) uint16_t s_col[4][IMG * 3];   // per-wave column sums of one cell row, by row byte
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int strip = blockIdx.x * 4 + wave;
 	const int f = blockIdx.y;
 	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
 	uint32_t* out = plane + (size_t)f * PLANE_WORDS;
-	const int y0 = strip * K1_ROWS;
+	uint32_t* cm = cellmean + (size_t)f * GRID_CELLS;
+	const int y_begin = strip == 0 ? 0 : OFFSET + strip * K1_CELLROWS * PITCH;
+	const int y_end = strip == K1_STRIPS - 1 ? IMG : OFFSET + (strip + 1) * K1_CELLROWS * PITCH;
+	const int total = (y_end - y_begin) + 2 * RAD;
 
-	uint32_t hring[2 * RAD + 1][8];   // horizontal sums of the last 2*RAD+1 rows (packed u16 pairs)
-	uint32_t gring[RAD + 1][4];       // gray of the last RAD+1 rows (packed bytes); [0] is the row being emitted
-	uint32_t V[8];
+	uint32_t ring[RING][8];
+	uint32_t C[8];
+	uint32_t acc_e[12], acc_o[12];    // per-byte column sums over a cell's inner rows: even / odd bytes of each dword, u16 x2
 #pragma unroll
-	for (int q = 0; q < 8; ++q) V[q] = 0;
+	for (int k = 0; k < RING; ++k)
 #pragma unroll
-	for (int k = 0; k < 2 * RAD + 1; ++k)
+		for (int i = 0; i < 8; ++i) ring[k][i] = 0;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) hring[k][q] = 0;
+	for (int i = 0; i < 8; ++i) C[i] = 0;
 #pragma unroll
-	for (int k = 0; k < RAD + 1; ++k)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) gring[k][q] = 0;
+	for (int k = 0; k < 12; ++k) { acc_e[k] = 0; acc_o[k] = 0; }
 
-	for (int t = 0; t < K1_ROWS + 2 * RAD; ++t) {
-		int y = y0 - RAD + t;
-		int yc = y < 0 ? 0 : (y >= IMG ? IMG - 1 : y);          // BORDER_REPLICATE on the thresholded image's source
-		uint32_t g[16];
-		if (PRE) sharp_row(frame, yc, lane, g);
-		else gray_row(frame, yc, lane, g);
+	auto clampy = [](int y) { return y < 0 ? 0 : (y >= IMG ? IMG - 1 : y); };   // BORDER_REPLICATE of the thresholded source
+#ifndef K1_DEPTH
+#define K1_DEPTH 3
+#endif
+	constexpr int DEPTH = K1_DEPTH;   // rows in flight per wave; RING % DEPTH == 0 keeps the buffer roles static after unrolling
+	static_assert(PRE || RING % DEPTH == 0, "prefetch depth must divide the ring size");
+	uint32_t buf[DEPTH][12];          // row t lives in buf[t % DEPTH] and is refilled with row t+DEPTH as soon as it is consumed
+	if (!PRE) {
+#pragma unroll
+		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, clampy(y_begin - RAD + k)), lane, buf[k]);
+	}
 
-		uint32_t ext[16 + 2 * RAD];
-		halo<RAD>(g, lane, false, ext);
-		// shift the rings, append the new row
+	for (int t0 = 0; t0 < total; t0 += RING) {
 #pragma unroll
-		for (int k = 0; k < 2 * RAD; ++k)
-#pragma unroll
-			for (int q = 0; q < 8; ++q) hring[k][q] = hring[k + 1][q];
-		hsum16<RAD>(ext, hring[2 * RAD]);
-#pragma unroll
-		for (int k = 0; k < RAD; ++k)
-#pragma unroll
-			for (int q = 0; q < 4; ++q) gring[k][q] = gring[k + 1][q];
-		pack_gray(g, gring[RAD]);
-#pragma unroll
-		for (int q = 0; q < 8; ++q) V[q] += hring[2 * RAD][q];
+		for (int s = 0; s < RING; ++s) {
+			const int t = t0 + s;
+			if (t < total) {
+				const int y = y_begin - RAD + t;
+				uint32_t (&d)[12] = buf[s % DEPTH];
+				uint32_t g[16];
+				if (PRE) sharp_row(frame, clampy(y), lane, d, g);
+				else gray16_dot(d, g);
 
-		if (t >= 2 * RAD) {
-			// emit row y - RAD: its gray is gring[0], its box sum is V
-			uint32_t bits = 0;
+				// colour column sums: rows 9r+9 .. 9r+14 are the inner rows of cell row r (cell top = 8 + 9r)
+				const bool in_grid = y >= y_begin && y < y_end && y >= OFFSET + 1 && y < OFFSET + DIM * PITCH;
+				const int ph = in_grid ? (y - OFFSET) % PITCH : 0;
+				if (ph >= 1 && ph <= 6) {
 #pragma unroll
-			for (int p = 0; p < 16; ++p) {
-				uint32_t gp = (gring[0][p >> 2] >> (8 * (p & 3))) & 0xFFu;
-				uint32_t vp = (V[p >> 1] >> (16 * (p & 1))) & 0xFFFFu;
-				bits |= (uint32_t)(gp * (uint32_t)N > vp + (uint32_t)(N / 2)) << (15 - p);
+					for (int k = 0; k < 12; ++k) { acc_e[k] += d[k] & 0x00FF00FFu; acc_o[k] += (d[k] >> 8) & 0x00FF00FFu; }
+				}
+				if (!PRE && t + DEPTH < total) load_row48(row_ptr(frame, clampy(y + DEPTH)), lane, d);   // d is dead: refill it
+
+				if (ph == 6) {
+					uint16_t* sc = s_col[wave];
+					uint2* dst = reinterpret_cast<uint2*>(sc + 48 * lane);
+#pragma unroll
+					for (int k = 0; k < 12; ++k) {
+						uint2 v;
+						v.x = (acc_e[k] & 0xFFFFu) | (acc_o[k] << 16);            // bytes 0,1 of dword k
+						v.y = (acc_e[k] >> 16) | (acc_o[k] & 0xFFFF0000u);        // bytes 2,3
+						dst[k] = v;
+						acc_e[k] = 0; acc_o[k] = 0;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					const int cell_row = (y - OFFSET) / PITCH;
+#pragma unroll
+					for (int half = 0; half < 2; ++half) {
+						const int c = lane + 64 * half;
+						if (c < DIM) {
+							const uint16_t* src = sc + 27 * c + 27;   // byte 3*(9c+9) of the row
+							uint32_t r = 0, gg = 0, b = 0;
+#pragma unroll
+							for (int k = 0; k < 6; ++k) { r += src[3 * k]; gg += src[3 * k + 1]; b += src[3 * k + 2]; }
+							cm[cell_row * DIM + c] = (r / 36u) | ((gg / 36u) << 8) | ((b / 36u) << 16);
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+				}
+
+				const bool emit = t >= 2 * RAD;
+				uint32_t bits = 0;
+				switch (s) {   // SLOT must be a compile-time constant; `s` is one after unrolling
+					case 0: bits = box_row<RAD, 0>(ring, C, g, emit); break;
+					case 1: bits = box_row<RAD, 1>(ring, C, g, emit); break;
+					case 2: bits = box_row<RAD, 2>(ring, C, g, emit); break;
+					case 3: bits = box_row<RAD, 3>(ring, C, g, emit); break;
+					case 4: bits = box_row<RAD, 4>(ring, C, g, emit); break;
+					case 5: bits = box_row<RAD, 5>(ring, C, g, emit); break;
+					case 6: bits = box_row<RAD, 6 % RING>(ring, C, g, emit); break;
+					default: bits = box_row<RAD, 7 % RING>(ring, C, g, emit); break;
+				}
+				if (emit) {
+					uint16_t* row16 = reinterpret_cast<uint16_t*>(out + (size_t)(y - RAD) * 32);
+					row16[lane ^ 1] = (uint16_t)bits;   // even lane = high half of word lane/2 (little-endian halves)
+				}
 			}
-			uint16_t* row16 = reinterpret_cast<uint16_t*>(out + (size_t)(y - RAD) * 32);
-			row16[lane ^ 1] = (uint16_t)bits;   // even lane = high half of word lane/2 (little-endian halves)
-#pragma unroll
-			for (int q = 0; q < 8; ++q) V[q] -= hring[0][q];
 		}
 	}
 }
@@ -905,9 +983,9 @@ __device__ __forceinline__ uint32_t best_color(float r, float g, float b, const 
 // K4: one wavefront per frame, after the symbol RS pass. Runs the chunk bookkeeping for blocks 0..39, then
 // CimbReader::init_ccm (CimbReader.cpp:169-267) for color_correction == 2, or the von Kries matrix for == 1.
 // ccm_out[f] = {9 floats, valid}; valid == 0 means "keep whatever the thread had" (resolved in k_colors).
-__global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rgb, Tables tb, const uint8_t* __restrict__ chunks,
-                                                  const uint8_t* __restrict__ rs_ok, int color_correction,
-                                                  FrameState* __restrict__ states, float* __restrict__ ccm_out)
+__global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ cellmean, Tables tb,
+                                                  const uint8_t* __restrict__ chunks, const uint8_t* __restrict__ rs_ok,
+                                                  int color_correction, FrameState* __restrict__ states, float* __restrict__ ccm_out)
 {
 	const int f = blockIdx.x, lane = threadIdx.x;
 	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
@@ -953,8 +1031,9 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 		const uint32_t expected = ((uint32_t)s_hdr[c][t >> 2] >> (6 - 2 * (t & 3))) & 3u;
 		const int cell = tb.stream_cell[3100 * c + t];
 		ushort2 xy = tb.cell_xy[cell];
-		uint32_t col[3];
-		mean6x6(frame, (int)xy.x + 1, (int)xy.y + 1, col);   // undrifted grid position + 1 (CimbReader.cpp:216-217)
+		// undrifted grid position + 1, 6x6 (CimbReader.cpp:216-217): exactly what K1 left in cellmean
+		const uint32_t mv = cellmean[(size_t)f * GRID_CELLS + (((int)xy.y - OFFSET) / PITCH) * DIM + ((int)xy.x - OFFSET) / PITCH];
+		const uint32_t col[3] = {mv & 0xFFu, (mv >> 8) & 0xFFu, (mv >> 16) & 0xFFu};
 		atomicAdd(&s_cnt[expected], 1u);
 		atomicAdd(&s_r[expected], col[0]);
 		atomicAdd(&s_g[expected], col[1]);
@@ -994,7 +1073,8 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 
 // K5: colour pass (Decoder.h:107-113; CimbReader.cpp:133-137; CimbDecoder.cpp:202-217). The matrix in force for frame
 // f is the newest valid one among frames <= f of this batch, else the context's carried one (slot `carry`).
-__global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb, Tables tb, const float* __restrict__ ccm_frames,
+__global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ cellmean, Tables tb,
+                                                const float* __restrict__ ccm_frames,
                                                 const float* __restrict__ carry, const uint32_t* __restrict__ flood_flag,
                                                 const int8_t* __restrict__ drift, uint8_t* __restrict__ colors,
                                                 float* __restrict__ ccm_used)
@@ -1013,9 +1093,15 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 	if (i >= NCELLS) return;
 	ushort2 xy = tb.cell_xy[i];
 	int x = (int)xy.x, y = (int)xy.y;
-	if (flood_flag[f]) { x += drift[((size_t)f * NCELLS + i) * 2]; y += drift[((size_t)f * NCELLS + i) * 2 + 1]; }
 	uint32_t col[3];
-	mean6x6(rgb + (size_t)f * FRAME_RGB, x + 1, y + 1, col);
+	if (flood_flag[f]) {
+		// the frame went through the exact flood pass: cells are read where their drift put them
+		x += drift[((size_t)f * NCELLS + i) * 2]; y += drift[((size_t)f * NCELLS + i) * 2 + 1];
+		mean6x6(rgb + (size_t)f * FRAME_RGB, x + 1, y + 1, col);
+	} else {
+		const uint32_t mv = cellmean[(size_t)f * GRID_CELLS + ((y - OFFSET) / PITCH) * DIM + (x - OFFSET) / PITCH];
+		col[0] = mv & 0xFFu; col[1] = (mv >> 8) & 0xFFu; col[2] = (mv >> 16) & 0xFFu;
+	}
 	colors[(size_t)f * NCELLS + i] = (uint8_t)best_color((float)col[0], (float)col[1], (float)col[2], s_m, s_m[9] != 0.0f);
 }
 
@@ -1073,6 +1159,7 @@ struct cimbar_hip_ctx {
 	uint8_t* d_rgb = nullptr;         // staging for host-resident input
 	size_t d_rgb_cap = 0;
 	uint32_t* d_plane = nullptr;
+	uint32_t* d_cellmean = nullptr;
 	uint8_t* d_symbols = nullptr;
 	uint8_t* d_colors = nullptr;
 	uint8_t* d_dist = nullptr;
@@ -1212,6 +1299,7 @@ int ensure_capacity(cimbar_hip_ctx* ctx, int n)
 	if (n <= ctx->cap) return 0;
 	size_t N = (size_t)n;
 	HIPCHK(regrow(ctx->d_plane, N * PLANE_WORDS));
+	HIPCHK(regrow(ctx->d_cellmean, N * GRID_CELLS));
 	HIPCHK(regrow(ctx->d_symbols, N * NCELLS));
 	HIPCHK(regrow(ctx->d_colors, N * NCELLS));
 	HIPCHK(regrow(ctx->d_dist, N * NCELLS));
@@ -1236,7 +1324,7 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	(void)hipSetDevice(ctx->device);
 	auto fr = [](void* p) { if (p) (void)hipFree(p); };
 	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.adj);
-	fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
+	fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
 	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
 	fr(ctx->d_masks); fr(ctx->d_total); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1256,9 +1344,9 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), st));
 	HIPCHK(mark());
 	{
-		dim3 g(IMG / K1_ROWS / 4, n);
-		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane);
-		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane);
+		dim3 g(K1_STRIPS / 4, n);
+		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean);
+		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean);
 	}
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_symbols, cell_grid, dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood);
@@ -1267,9 +1355,9 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(mark());
 	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, n, 0, d_chunks, ctx->d_rs_ok, 0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames);
+	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used);
+	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used);
 	HIPCHK(mark());
 	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
 	HIPCHK(mark());

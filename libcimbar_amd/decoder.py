@@ -39,7 +39,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("CIMBAR_HIP_LIB") or LIB_PATH   # CIMBAR_HIP_LIB: A/B-test another build of the same ABI
     if not os.path.exists(p):
         raise CimbarHipError(f"{p} not found: build it with `python -m libcimbar_amd.build` (hipcc, gfx950). "
                              "There is no CPU fallback for the decode path.")
