@@ -119,7 +119,6 @@ def main():
     chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
     masks = torch.zeros((n,), dtype=torch.int32, device=dev)
     dec = HipDecoder(local_rank)
-    dec.enable_timing(True)
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -155,7 +154,9 @@ def main():
     if not ok:
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
-    # per-kernel times of one more (profiled) step: HIP events on the launch stream, recorded inside the library
+    # per-kernel times of a few more steps: HIP events on the launch stream, recorded inside the library. With timing on,
+    # the library runs the batch un-sliced on one stream (one launch per kernel), so each figure is one kernel's duration.
+    dec.enable_timing(True)
     reps = 5
     for _ in range(reps):
         dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)

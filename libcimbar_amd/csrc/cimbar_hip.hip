@@ -19,6 +19,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,6 +77,12 @@ struct Tables {
 //           (CimbReader.cpp:133-137,216-217). Strips are aligned to the cell grid (16 strips x 7 cell rows), so a cell's
 //           six inner rows always belong to one wave: per-byte column sums accumulate in registers over those rows and
 //           are regrouped into cells through a 6 KiB LDS transpose once per cell row.
+#ifndef K1_ABLATE
+#define K1_ABLATE 0   // experiment switch (timing ablations only); 0 in the product
+#endif
+#ifndef K1_STORE
+#define K1_STORE 2    // how the 16 result bits per lane reach memory: 0 = 2-byte stores, 1 = dword per lane pair, 2 = 16 B per 8 lanes
+#endif
 constexpr int K1_STRIPS = 16, K1_CELLROWS = DIM / K1_STRIPS;   // 7 cell rows = 63 pixel rows per strip (+8 px margin at both ends)
 constexpr int GRID_CELLS = DIM * DIM;
 
@@ -99,11 +106,13 @@ __device__ __forceinline__ void gray16(const uint32_t d[12], uint32_t g[16])
 }
 
 // 16 gray pixels straight from the 12 raw dwords with v_dot4_u32_u8: pixel p starts at byte 3p; the dot product's fourth
-// coefficient is 0, so the dword may carry the next pixel's first byte. Coefficients split hi/lo byte:
-// 9798 = 38*256+70, 19235 = 75*256+35, 3735 = 14*256+151.
-__device__ __forceinline__ void gray16_dot(const uint32_t d[12], uint32_t g[16])
+// coefficient is 0, so the dword may carry the next pixel's first byte. The 15-bit coefficients are split c = hi*128 + lo
+// (9798 = 76*128+70, 19235 = 150*128+35, 3735 = 29*128+23) and the low dot product is doubled, so that
+//   T = (hi_dot << 8) + 2*lo_dot + 32768 = 2 * (R*9798 + G*19235 + B*3735 + 16384)   and   gray = T >> 16 = byte 2 of T.
+// Leaving the result byte-aligned lets one v_perm_b32 pack two pixels into a u16 pair.
+__device__ __forceinline__ void gray16_T(const uint32_t d[12], uint32_t T[16])
 {
-	constexpr uint32_t LO = 70u | (35u << 8) | (151u << 16), HI = 38u | (75u << 8) | (14u << 16);
+	constexpr uint32_t LO2 = 140u | (70u << 8) | (46u << 16), HI = 76u | (150u << 8) | (29u << 16);
 #pragma unroll
 	for (int p = 0; p < 16; ++p) {
 		const int w = (3 * p) >> 2, sh = (3 * p) & 3;
@@ -111,10 +120,28 @@ __device__ __forceinline__ void gray16_dot(const uint32_t d[12], uint32_t g[16])
 		if (sh == 0) v = d[w];
 		else if (w == 11) v = d[11] >> (8 * sh);
 		else v = __builtin_amdgcn_alignbyte(d[w + 1], d[w], sh);
-		uint32_t lo = __builtin_amdgcn_udot4(v, LO, 16384u, false);
-		uint32_t hi = __builtin_amdgcn_udot4(v, HI, 0u, false);
-		g[p] = ((hi << 8) + lo) >> 15;
+		const uint32_t lo = __builtin_amdgcn_udot4(v, LO2, 32768u, false);
+		const uint32_t hi = __builtin_amdgcn_udot4(v, HI, 0u, false);
+		T[p] = (hi << 8) + lo;
 	}
+}
+__device__ __forceinline__ void gray16_dot(const uint32_t d[12], uint32_t g[16])
+{
+	uint32_t T[16];
+	gray16_T(d, T);
+#pragma unroll
+	for (int p = 0; p < 16; ++p) g[p] = T[p] >> 16;
+}
+// (pixel i | pixel i+8 << 16) from the byte-2 results of gray16_T: one v_perm_b32 per pair
+__device__ __forceinline__ void pairs_from_T(const uint32_t T[16], uint32_t G[8])
+{
+#pragma unroll
+	for (int i = 0; i < 8; ++i) G[i] = __builtin_amdgcn_perm(T[i + 8], T[i], 0x0c060c02u);   // bytes: [T_i.b2, 0, T_{i+8}.b2, 0]
+}
+__device__ __forceinline__ void pairs_from_g(const uint32_t g[16], uint32_t G[8])
+{
+#pragma unroll
+	for (int i = 0; i < 8; ++i) G[i] = g[i] | (g[i + 8] << 16);
 }
 
 // lane l <- lane l-1 (lane 0 keeps `edge`), lane l <- lane l+1 (lane 63 keeps `edge`): DPP wave shifts, one VALU op each
@@ -151,16 +178,15 @@ __device__ __forceinline__ void sharp_row(const uint8_t* __restrict__ frame, int
 //   C    : per-column sums of the newest 2*RAD+1 rows
 // emit: row (y - RAD) has its full window -> 16 result bits for this lane.
 template <int RAD, int SLOT>
-__device__ __forceinline__ uint32_t box_row(uint32_t (&ring)[2 * RAD + 2][8], uint32_t (&C)[8], const uint32_t g[16], bool emit)
+__device__ __forceinline__ uint32_t box_row(uint32_t (&ring)[2 * RAD + 2][8], uint32_t (&C)[8], const uint32_t G[8], bool emit)
 {
 	constexpr int RING = 2 * RAD + 2, R = 2 * RAD + 1, N = R * R;
 	constexpr int OLD = (SLOT + 1) % RING;            // row y - (2*RAD+1), leaving the window
 	constexpr int CTR = (SLOT + RING - RAD) % RING;   // row y - RAD, the one being emitted
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		const uint32_t G = g[i] | (g[i + 8] << 16);
-		C[i] += G - ring[OLD][i];
-		ring[SLOT][i] = G;
+		C[i] += G[i] - ring[OLD][i];
+		ring[SLOT][i] = G[i];
 	}
 	if (!emit) return 0;
 
@@ -187,7 +213,7 @@ __device__ __forceinline__ uint32_t box_row(uint32_t (&ring)[2 * RAD + 2][8], ui
 		if (i > 0) S += X[i + 2 * RAD] - X[i - 1];
 		// N*g > S + N/2  <=>  bit 15 of (N*g + 0x8000 - N/2 - 1 - S), per half; no field under/overflows (|.| <= 12495)
 		const uint32_t r = __umul24(ring[CTR][i], (uint32_t)N) + K - S;
-		M |= (r & 0x80008000u) >> i;
+		M |= (r >> i) & (0x80008000u >> i);   // v_lshrrev + v_and_or
 	}
 	return (M & 0xFF00u) | (M >> 24);   // bit 15-p = pixel p
 }
@@ -197,13 +223,14 @@ template <int RAD, bool PRE>
 #define K1_WAVES 3
 #endif
 __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
-                                                                uint32_t* __restrict__ cellmean)
+                                                                uint32_t* __restrict__ cellmean, int f0)
 {
 	constexpr int RING = 2 * RAD + 2;
 	__shared__ __attribute__((aligned(16))) uint16_t s_col[4][IMG * 3];   // per-wave column sums of one cell row, by row byte
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps every row index / address base scalar
 	const int strip = blockIdx.x * 4 + wave;
-	const int f = blockIdx.y;
+	const int f = f0 + blockIdx.y;
 	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
 	uint32_t* out = plane + (size_t)f * PLANE_WORDS;
 	uint32_t* cm = cellmean + (size_t)f * GRID_CELLS;
@@ -235,69 +262,106 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, clampy(y_begin - RAD + k)), lane, buf[k]);
 	}
 
+	// Straight-line body: every unrolled step runs unconditionally (rows past the strip are clamped re-reads whose results
+	// are never stored), so the refill of a consumed buffer is an unconditional load into the same registers -- no phi,
+	// no copy, and the compiler's vmcnt waits only ever cover the oldest row in flight.
+	const int y_last = clampy(y_end - 1 + RAD);
 	for (int t0 = 0; t0 < total; t0 += RING) {
 #pragma unroll
 		for (int s = 0; s < RING; ++s) {
 			const int t = t0 + s;
-			if (t < total) {
-				const int y = y_begin - RAD + t;
-				uint32_t (&d)[12] = buf[s % DEPTH];
+			const int y = y_begin - RAD + t;
+			uint32_t (&d)[12] = buf[s % DEPTH];
+			uint32_t G[8];
+			if (PRE) {
 				uint32_t g[16];
-				if (PRE) sharp_row(frame, clampy(y), lane, d, g);
-				else gray16_dot(d, g);
-
-				// colour column sums: rows 9r+9 .. 9r+14 are the inner rows of cell row r (cell top = 8 + 9r)
-				const bool in_grid = y >= y_begin && y < y_end && y >= OFFSET + 1 && y < OFFSET + DIM * PITCH;
-				const int ph = in_grid ? (y - OFFSET) % PITCH : 0;
-				if (ph >= 1 && ph <= 6) {
+				sharp_row(frame, clampy(y < y_last ? y : y_last), lane, d, g);
+				pairs_from_g(g, G);
+			} else {
+				if (K1_ABLATE & 8) {
 #pragma unroll
-					for (int k = 0; k < 12; ++k) { acc_e[k] += d[k] & 0x00FF00FFu; acc_o[k] += (d[k] >> 8) & 0x00FF00FFu; }
+					for (int i = 0; i < 8; ++i) G[i] = d[i] & 0x00FF00FFu;
+				} else {
+					uint32_t T[16];
+					gray16_T(d, T);
+					pairs_from_T(T, G);
 				}
-				if (!PRE && t + DEPTH < total) load_row48(row_ptr(frame, clampy(y + DEPTH)), lane, d);   // d is dead: refill it
+			}
 
-				if (ph == 6) {
-					uint16_t* sc = s_col[wave];
-					uint2* dst = reinterpret_cast<uint2*>(sc + 48 * lane);
+			// colour column sums: rows 9r+9 .. 9r+14 are the inner rows of cell row r (cell top = 8 + 9r)
+			const bool in_grid = y >= y_begin && y < y_end && y >= OFFSET + 1 && y < OFFSET + DIM * PITCH;
+			const int ph = in_grid ? (y - OFFSET) % PITCH : 0;
+			if (!(K1_ABLATE & 1) && ph >= 1 && ph <= 6) {
 #pragma unroll
-					for (int k = 0; k < 12; ++k) {
-						uint2 v;
-						v.x = (acc_e[k] & 0xFFFFu) | (acc_o[k] << 16);            // bytes 0,1 of dword k
-						v.y = (acc_e[k] >> 16) | (acc_o[k] & 0xFFFF0000u);        // bytes 2,3
-						dst[k] = v;
-						acc_e[k] = 0; acc_o[k] = 0;
+				for (int k = 0; k < 12; ++k) {
+					acc_e[k] += d[k] & 0x00FF00FFu;
+					acc_o[k] += __builtin_amdgcn_perm(0u, d[k], 0x0c030c01u);   // (d >> 8) & 0x00FF00FF in one op
+				}
+			}
+			if (!PRE) {   // d is dead: refill it with row t+DEPTH
+				const int yn = y + DEPTH;
+				load_row48(row_ptr(frame, clampy(yn < y_last ? yn : y_last)), lane, d);
+			}
+
+			if (!(K1_ABLATE & 1) && ph == 6) {
+				uint16_t* sc = s_col[wave];
+				uint2* dst = reinterpret_cast<uint2*>(sc + 48 * lane);
+#pragma unroll
+				for (int k = 0; k < 12; ++k) {
+					uint2 v;
+					v.x = (acc_e[k] & 0xFFFFu) | (acc_o[k] << 16);            // bytes 0,1 of dword k
+					v.y = (acc_e[k] >> 16) | (acc_o[k] & 0xFFFF0000u);        // bytes 2,3
+					dst[k] = v;
+					acc_e[k] = 0; acc_o[k] = 0;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				const int cell_row = (y - OFFSET) / PITCH;
+#pragma unroll
+				for (int half = 0; half < 2; ++half) {
+					const int c = lane + 64 * half;
+					if (c < DIM) {
+						const uint16_t* src = sc + 27 * c + 27;   // byte 3*(9c+9) of the row
+						uint32_t r = 0, gg = 0, b = 0;
+#pragma unroll
+						for (int k = 0; k < 6; ++k) { r += src[3 * k]; gg += src[3 * k + 1]; b += src[3 * k + 2]; }
+						cm[cell_row * DIM + c] = (r / 36u) | ((gg / 36u) << 8) | ((b / 36u) << 16);
 					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-					__builtin_amdgcn_wave_barrier();
-					const int cell_row = (y - OFFSET) / PITCH;
-#pragma unroll
-					for (int half = 0; half < 2; ++half) {
-						const int c = lane + 64 * half;
-						if (c < DIM) {
-							const uint16_t* src = sc + 27 * c + 27;   // byte 3*(9c+9) of the row
-							uint32_t r = 0, gg = 0, b = 0;
-#pragma unroll
-							for (int k = 0; k < 6; ++k) { r += src[3 * k]; gg += src[3 * k + 1]; b += src[3 * k + 2]; }
-							cm[cell_row * DIM + c] = (r / 36u) | ((gg / 36u) << 8) | ((b / 36u) << 16);
-						}
-					}
-					__builtin_amdgcn_wave_barrier();
 				}
+				__builtin_amdgcn_wave_barrier();
+			}
 
-				const bool emit = t >= 2 * RAD;
-				uint32_t bits = 0;
-				switch (s) {   // SLOT must be a compile-time constant; `s` is one after unrolling
-					case 0: bits = box_row<RAD, 0>(ring, C, g, emit); break;
-					case 1: bits = box_row<RAD, 1>(ring, C, g, emit); break;
-					case 2: bits = box_row<RAD, 2>(ring, C, g, emit); break;
-					case 3: bits = box_row<RAD, 3>(ring, C, g, emit); break;
-					case 4: bits = box_row<RAD, 4>(ring, C, g, emit); break;
-					case 5: bits = box_row<RAD, 5>(ring, C, g, emit); break;
-					case 6: bits = box_row<RAD, 6 % RING>(ring, C, g, emit); break;
-					default: bits = box_row<RAD, 7 % RING>(ring, C, g, emit); break;
-				}
-				if (emit) {
+			uint32_t bits = 0;
+			switch (s) {   // SLOT must be a compile-time constant; `s` is one after unrolling
+				case 0: bits = box_row<RAD, 0>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 1: bits = box_row<RAD, 1>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 2: bits = box_row<RAD, 2>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 3: bits = box_row<RAD, 3>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 4: bits = box_row<RAD, 4>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 5: bits = box_row<RAD, 5>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 6: bits = box_row<RAD, 6 % RING>(ring, C, G, true); break;
+				default: bits = box_row<RAD, 7 % RING>(ring, C, G, true); break;
+			}
+			if (K1_STORE == 0) {
+				if (((K1_ABLATE & 2) ? (bits == 0x12345u) : true) && t >= 2 * RAD && t < total) {
 					uint16_t* row16 = reinterpret_cast<uint16_t*>(out + (size_t)(y - RAD) * 32);
 					row16[lane ^ 1] = (uint16_t)bits;   // even lane = high half of word lane/2 (little-endian halves)
+				}
+			} else if (K1_STORE == 1) {
+				// word j = (lane 2j bits << 16) | lane 2j+1 bits; even lanes store one dword each
+				const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+				if (t >= 2 * RAD && t < total && !(lane & 1)) out[(size_t)(y - RAD) * 32 + (lane >> 1)] = (bits << 16) | nb;
+			} else {
+				// gather the 8 x 16 bits of lanes 8k..8k+7 into lane 8k and store 16 bytes (columns 128k .. 128k+127 of the row)
+				const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xf, 0xf, true);   // lane^1
+				const uint32_t w0 = (lane & 1) ? ((nb << 16) | bits) : ((bits << 16) | nb);                        // word of lanes (2j,2j+1), in both
+				const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x4E, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]: the quad's other word
+				// lanes 4q..4q+3: lane 4q has w0 = word(2q), w1 = word(2q+1). Bring the next quad's two words over (row_shl:4).
+				const uint32_t w2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x104, 0xf, 0xf, true);     // row_shl:4 -> lane l gets lane l+4
+				const uint32_t w3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x104, 0xf, 0xf, true);
+				if (t >= 2 * RAD && t < total && !(lane & 7)) {
+					uint4 v; v.x = w0; v.y = w1; v.z = w2; v.w = w3;
+					*reinterpret_cast<uint4*>(out + (size_t)(y - RAD) * 32 + (lane >> 3) * 4) = v;
 				}
 			}
 		}
@@ -348,41 +412,69 @@ __device__ __forceinline__ bool is_seed(int i)
 	       i == NCELLS - 1 - TOP_CELLS || i == NCELLS - TOP_CELLS - DIM;
 }
 
+// minimum of a 32-bit value over the wave (ds_bpermute butterflies; used only on the rare slow path)
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o < v ? o : v; }
+	return v;
+}
+
 // K2: every cell evaluated at drift (0,0). If, for every cell, no shifted window beats the centre one (4 side windows
 // for ordinary cells, all 8 for the flood seeds, which may be popped in 9-window mode), the reference's flood visits
 // every cell at drift (0,0) with cooldown 4|0xFE whatever its heap order, so symbol = argmin_tile popcnt(centre ^ tile)
 // exactly (DESIGN.md "fast path"). Otherwise flag the frame for K2b.
+// One lane per cell for the centre match (the common case ends there: distance 0). The few cells with a non-zero centre
+// distance are then re-examined one at a time by the whole wave: their window rows are broadcast, the 4 (+4) shifted
+// hashes are formed once on uniform data and the 64 lanes split the (window, tile) pairs.
 __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ plane, Tables tb, uint8_t* __restrict__ symbols,
-                                                 uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag)
+                                                 uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag, int f0)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	const int f = blockIdx.y;
-	if (i >= NCELLS) return;
+	const int f = f0 + blockIdx.y;
+	const int lane = threadIdx.x & 63;
+	const bool live = i < NCELLS;
 	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
-	ushort2 xy = tb.cell_xy[i];
 	uint32_t rows[10];
-	window_rows(pl, (int)xy.x - 1, (int)xy.y - 1, rows);
+	uint32_t dc = 0;
+	if (live) {
+		ushort2 xy = tb.cell_xy[i];
+		window_rows(pl, (int)xy.x - 1, (int)xy.y - 1, rows);
+		const uint32_t centre = best_tile(window_hash(rows, 4));
+		dc = centre >> 4;
+		symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
+		if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
+	} else {
+#pragma unroll
+		for (int k = 0; k < 10; ++k) rows[k] = 0;
+	}
 
-	uint32_t centre = best_tile(window_hash(rows, 4));
-	uint32_t dc = centre >> 4;
+	unsigned long long todo = __ballot(live && dc != 0);
+	if (todo == 0) return;
+	const uint64_t my_tile = c_tile[lane & 15];
+	const int grp = lane >> 4;
 	bool shifted = false;
-	if (dc != 0) {
-		uint32_t other = 0xFFFFu;
-		const int side[4] = {5, 7, 3, 1};
+	while (todo) {
+		const int L = __builtin_ctzll(todo);
+		todo &= todo - 1;
+		uint32_t ur[10];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { uint32_t b = best_tile(window_hash(rows, side[k])); other = b < other ? b : other; }
-		if (is_seed(i)) {
-			const int corner[4] = {8, 0, 2, 6};
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { uint32_t b = best_tile(window_hash(rows, corner[k])); other = b < other ? b : other; }
+		for (int k = 0; k < 10; ++k) ur[k] = (uint32_t)__builtin_amdgcn_readlane((int)rows[k], L);
+		const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dc, L);
+		const int cell = blockIdx.x * 256 + (threadIdx.x & ~63) + L;
+		// side windows 5,7,3,1 on lane groups 0..3 (uniform hashes, per-lane select)
+		const uint64_t h5 = window_hash(ur, 5), h7 = window_hash(ur, 7), h3 = window_hash(ur, 3), h1 = window_hash(ur, 1);
+		uint64_t h = grp == 0 ? h5 : (grp == 1 ? h7 : (grp == 2 ? h3 : h1));
+		uint32_t best = (uint32_t)__popcll(h ^ my_tile);
+		if (is_seed(cell)) {
+			const uint64_t h8 = window_hash(ur, 8), h0 = window_hash(ur, 0), h2 = window_hash(ur, 2), h6 = window_hash(ur, 6);
+			h = grp == 0 ? h8 : (grp == 1 ? h0 : (grp == 2 ? h2 : h6));
+			const uint32_t d2 = (uint32_t)__popcll(h ^ my_tile);
+			best = d2 < best ? d2 : best;
 		}
-		shifted = (other >> 4) < dc;
+		if (wave_min(best) < dL) shifted = true;
 	}
-	symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
-	if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
-	if (__any(shifted)) {
-		if ((threadIdx.x & 63) == 0) atomicOr(&flood_flag[f], 1u);
-	}
+	if (shifted && lane == 0) atomicOr(&flood_flag[f], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ K2b exact flood
@@ -458,9 +550,9 @@ __device__ __forceinline__ void offer(int next, uint32_t* h, int& hn, uint32_t* 
 
 __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane, Tables tb, FloodScratch sc,
                                               const uint32_t* __restrict__ flood_flag, uint8_t* __restrict__ symbols,
-                                              int8_t* __restrict__ drift, uint8_t* __restrict__ dist_out)
+                                              int8_t* __restrict__ drift, uint8_t* __restrict__ dist_out, int f0)
 {
-	const int f = blockIdx.x, lane = threadIdx.x;
+	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	if (!flood_flag[f]) return;
 	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
 	uint32_t* h = sc.heap + (size_t)f * HEAP_CAP;
@@ -577,11 +669,22 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 // reed_solomon_stream.h:54-77 -> libcorrect decode.c:299-379, one 155-byte block per wavefront. The block is gathered
 // straight out of the per-cell symbol (4 bit, 2 cells/byte) or colour (2 bit, 4 cells/byte) arrays through the inverse
 // interleave map (Decoder.h:91-96,112; bitbuffer.h:62-84), so the 6200/3100-byte pre-RS streams never exist in memory.
+// XOR of a 32-bit value over all 64 lanes (result uniform): 4 DPP butterflies inside each 16-lane row, then the four rows
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+	v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm:[1,0,3,2]
+	v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm:[2,3,0,1]
+	v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+	v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);   // row_mirror
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
+	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 struct RsShared {
 	uint8_t exp[512];
 	uint8_t log[256];
 	uint8_t enc[4][160];      // block in transmit order
-	uint8_t synd[4][32];
+	__attribute__((aligned(4))) uint8_t synd[4][32];
 	uint8_t loc[4][72];
 	uint8_t last[4][72];
 	uint8_t evalr[4][32];
@@ -602,7 +705,7 @@ __device__ __forceinline__ uint8_t gf_eval(const RsShared& s, const uint8_t* coe
 }
 
 template <int BITS>   // 4: symbol stream, 2: colour stream
-__global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, Tables tb, int nframes, int first_chunk,
+__global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, Tables tb, int f0, int nframes, int first_chunk,
                                             uint8_t* __restrict__ chunks, uint8_t* __restrict__ rs_ok, int ok_offset)
 {
 	constexpr int NBLK = (BITS == 4) ? SYM_BLOCKS : COL_BLOCKS;
@@ -614,36 +717,64 @@ __global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, T
 
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int gb = blockIdx.x * 4 + wv;                 // global block number over the batch
-	const int f = gb / NBLK, b = gb % NBLK;
-	if (f >= nframes) return;
+	const int b = gb % NBLK;
+	if (gb / NBLK >= nframes) return;
+	const int f = f0 + gb / NBLK;
 	const uint8_t* cf = cells + (size_t)f * NCELLS;
 	uint8_t* enc = s.enc[wv];
 
-	// gather: stream byte B = 155*b + k packs stream cells PER_BYTE*B .. +PER_BYTE-1, first cell in the high bits
-	for (int k = lane; k < RS_BLOCK; k += 64) {
-		int sidx = (RS_BLOCK * b + k) * PER_BYTE;
-		uint32_t v = 0;
+	// gather: stream byte B = 155*b + k packs stream cells PER_BYTE*B .. +PER_BYTE-1, first cell in the high bits.
+	// Lane l owns bytes l, l+64, l+128 of the block (registers) and also parks them in LDS for the correction / output steps.
+	uint32_t mine[3];
 #pragma unroll
-		for (int q = 0; q < PER_BYTE; ++q) v = (v << BITS) | (cf[tb.stream_cell[sidx + q]] & ((1u << BITS) - 1u));
-		enc[k] = (uint8_t)v;
-	}
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_s_waitcnt(0);   // lgkmcnt/vmcnt drain: LDS writes above visible to the wave's later reads
-
-	// syndromes S_j = r(alpha^(j+1)), r(x) = sum_i enc[154-i] x^i  (decode.c:12-28): Horner from the highest degree
-	if (lane < RS_PARITY) {
-		const unsigned lr = (unsigned)lane + 1u;
-		uint8_t acc = 0;
-		for (int k = 0; k < RS_BLOCK; ++k) {
-			acc = acc ? s.exp[(unsigned)s.log[acc] + lr] : 0;
-			acc ^= enc[k];
+	for (int r = 0; r < 3; ++r) {
+		const int k = lane + 64 * r;
+		uint32_t v = 0;
+		if (k < RS_BLOCK) {
+			const int sidx = (RS_BLOCK * b + k) * PER_BYTE;
+#pragma unroll
+			for (int q = 0; q < PER_BYTE; ++q) v = (v << BITS) | (cf[tb.stream_cell[sidx + q]] & ((1u << BITS) - 1u));
+			enc[k] = (uint8_t)v;
 		}
-		s.synd[wv][lane] = acc;
+		mine[r] = v;
+	}
+
+	// syndromes S_j = r(alpha^(j+1)), r(x) = sum_i enc[154-i] x^i (decode.c:12-28), evaluated term-parallel: lane's byte k
+	// contributes enc[k] * alpha^((j+1)*(154-k)); the 64 partial sums are XOR-reduced across the wave, four syndromes
+	// (one per byte of a dword) at a time. No dependent chain of table look-ups, every lane busy.
+	uint32_t lg[3], stp[3], rr[3];
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const int k = lane + 64 * r;
+		lg[r] = s.log[mine[r] & 0xFFu];
+		stp[r] = k < RS_BLOCK ? (uint32_t)(RS_BLOCK - 1 - k) : 0u;
+		rr[r] = 0;
+	}
+	uint32_t any_nonzero = 0;
+#pragma unroll
+	for (int jg = 0; jg < (RS_PARITY + 3) / 4; ++jg) {
+		uint32_t packed = 0;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			if (4 * jg + q < RS_PARITY) {
+				uint32_t part = 0;
+#pragma unroll
+				for (int r = 0; r < 3; ++r) {
+					rr[r] += stp[r];
+					rr[r] -= rr[r] >= 255u ? 255u : 0u;
+					const uint32_t term = s.exp[lg[r] + rr[r]];
+					part ^= mine[r] ? term : 0u;
+				}
+				packed |= part << (8 * q);
+			}
+		}
+		const uint32_t red = wave_xor(packed);
+		any_nonzero |= red;
+		if (lane == 0) reinterpret_cast<uint32_t*>(s.synd[wv])[jg] = red;
 	}
 	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_s_waitcnt(0);
-	const uint8_t mysynd = lane < RS_PARITY ? s.synd[wv][lane] : 0;
-	const bool all_zero = !__any(mysynd != 0);
+	__builtin_amdgcn_s_waitcnt(0);   // LDS writes above visible to the wave's later reads
+	const bool all_zero = any_nonzero == 0;
 
 	int ok = 1;
 	if (!all_zero) {
@@ -985,9 +1116,9 @@ __device__ __forceinline__ uint32_t best_color(float r, float g, float b, const 
 // ccm_out[f] = {9 floats, valid}; valid == 0 means "keep whatever the thread had" (resolved in k_colors).
 __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ cellmean, Tables tb,
                                                   const uint8_t* __restrict__ chunks, const uint8_t* __restrict__ rs_ok,
-                                                  int color_correction, FrameState* __restrict__ states, float* __restrict__ ccm_out)
+                                                  int color_correction, FrameState* __restrict__ states, float* __restrict__ ccm_out, int f0)
 {
-	const int f = blockIdx.x, lane = threadIdx.x;
+	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
 	const uint8_t* fc = chunks + (size_t)f * FRAME_BYTES;
 	__shared__ uint8_t s_hdr[4][6];      // predicted header of colour chunk c (CimbReader.cpp:188-227)
@@ -1077,9 +1208,9 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
                                                 const float* __restrict__ ccm_frames,
                                                 const float* __restrict__ carry, const uint32_t* __restrict__ flood_flag,
                                                 const int8_t* __restrict__ drift, uint8_t* __restrict__ colors,
-                                                float* __restrict__ ccm_used)
+                                                float* __restrict__ ccm_used, int f0)
 {
-	const int f = blockIdx.y;
+	const int f = f0 + blockIdx.y;
 	__shared__ float s_m[10];
 	if (threadIdx.x == 0) {
 		int g = f;
@@ -1108,9 +1239,9 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 // K7: chunk bookkeeping for the colour blocks, final mask, zero the slots of dropped chunks, per-frame good bytes
 __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
                                                   uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
-                                                  unsigned long long* __restrict__ total_good)
+                                                  unsigned long long* __restrict__ total_good, int f0)
 {
-	const int f = blockIdx.x, lane = threadIdx.x;
+	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	__shared__ uint32_t s_mask;
 	if (lane == 0) {
 		FrameState st = states[f];
@@ -1332,36 +1463,37 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	delete ctx;
 }
 
-// enqueue the whole pipeline for n device-resident frames
+// enqueue the whole pipeline for n device-resident frames on stream `st`
 int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks)
 {
 	const bool tm = ctx->timing;
 	int evi = 0;
 	auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(ctx->ev[evi++], st) : hipSuccess; };
 	const dim3 cell_grid((NCELLS + 255) / 256, n);
+	const int f0 = 0;   // kernels index frames as f0 + block index, so a caller may also run a sub-range of a resident batch
 
 	HIPCHK(hipMemsetAsync(ctx->d_flood, 0, sizeof(uint32_t) * (size_t)n, st));
 	HIPCHK(hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), st));
 	HIPCHK(mark());
 	{
 		dim3 g(K1_STRIPS / 4, n);
-		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean);
-		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean);
+		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, f0);
+		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, f0);
 	}
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_symbols, cell_grid, dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood);
+	hipLaunchKernelGGL(k_symbols, cell_grid, dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_flood, dim3(n), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols, ctx->d_drift, ctx->d_dist);
+	hipLaunchKernelGGL(k_flood, dim3(n), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols, ctx->d_drift, ctx->d_dist, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, n, 0, d_chunks, ctx->d_rs_ok, 0);
+	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, f0, n, 0, d_chunks, ctx->d_rs_ok, 0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames);
+	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used);
+	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
+	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, f0, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total);
+	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total, f0);
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_ccm_carry, dim3(1), dim3(64), 0, st, ctx->d_ccm_used, n - 1, ctx->d_carry);
 	HIPCHK(mark());
