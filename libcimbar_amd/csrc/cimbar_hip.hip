@@ -77,12 +77,6 @@ struct Tables {
 //           (CimbReader.cpp:133-137,216-217). Strips are aligned to the cell grid (16 strips x 7 cell rows), so a cell's
 //           six inner rows always belong to one wave: per-byte column sums accumulate in registers over those rows and
 //           are regrouped into cells through a 6 KiB LDS transpose once per cell row.
-#ifndef K1_ABLATE
-#define K1_ABLATE 0   // experiment switch (timing ablations only); 0 in the product
-#endif
-#ifndef K1_STORE
-#define K1_STORE 2    // how the 16 result bits per lane reach memory: 0 = 2-byte stores, 1 = dword per lane pair, 2 = 16 B per 8 lanes
-#endif
 constexpr int K1_STRIPS = 16, K1_CELLROWS = DIM / K1_STRIPS;   // 7 cell rows = 63 pixel rows per strip (+8 px margin at both ends)
 constexpr int GRID_CELLS = DIM * DIM;
 
@@ -278,20 +272,15 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 				sharp_row(frame, clampy(y < y_last ? y : y_last), lane, d, g);
 				pairs_from_g(g, G);
 			} else {
-				if (K1_ABLATE & 8) {
-#pragma unroll
-					for (int i = 0; i < 8; ++i) G[i] = d[i] & 0x00FF00FFu;
-				} else {
-					uint32_t T[16];
-					gray16_T(d, T);
-					pairs_from_T(T, G);
-				}
+				uint32_t T[16];
+				gray16_T(d, T);
+				pairs_from_T(T, G);
 			}
 
 			// colour column sums: rows 9r+9 .. 9r+14 are the inner rows of cell row r (cell top = 8 + 9r)
 			const bool in_grid = y >= y_begin && y < y_end && y >= OFFSET + 1 && y < OFFSET + DIM * PITCH;
 			const int ph = in_grid ? (y - OFFSET) % PITCH : 0;
-			if (!(K1_ABLATE & 1) && ph >= 1 && ph <= 6) {
+			if (ph >= 1 && ph <= 6) {
 #pragma unroll
 				for (int k = 0; k < 12; ++k) {
 					acc_e[k] += d[k] & 0x00FF00FFu;
@@ -303,7 +292,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 				load_row48(row_ptr(frame, clampy(yn < y_last ? yn : y_last)), lane, d);
 			}
 
-			if (!(K1_ABLATE & 1) && ph == 6) {
+			if (ph == 6) {
 				uint16_t* sc = s_col[wave];
 				uint2* dst = reinterpret_cast<uint2*>(sc + 48 * lane);
 #pragma unroll
@@ -333,25 +322,16 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 
 			uint32_t bits = 0;
 			switch (s) {   // SLOT must be a compile-time constant; `s` is one after unrolling
-				case 0: bits = box_row<RAD, 0>(ring, C, G, !(K1_ABLATE & 4)); break;
-				case 1: bits = box_row<RAD, 1>(ring, C, G, !(K1_ABLATE & 4)); break;
-				case 2: bits = box_row<RAD, 2>(ring, C, G, !(K1_ABLATE & 4)); break;
-				case 3: bits = box_row<RAD, 3>(ring, C, G, !(K1_ABLATE & 4)); break;
-				case 4: bits = box_row<RAD, 4>(ring, C, G, !(K1_ABLATE & 4)); break;
-				case 5: bits = box_row<RAD, 5>(ring, C, G, !(K1_ABLATE & 4)); break;
+				case 0: bits = box_row<RAD, 0>(ring, C, G, true); break;
+				case 1: bits = box_row<RAD, 1>(ring, C, G, true); break;
+				case 2: bits = box_row<RAD, 2>(ring, C, G, true); break;
+				case 3: bits = box_row<RAD, 3>(ring, C, G, true); break;
+				case 4: bits = box_row<RAD, 4>(ring, C, G, true); break;
+				case 5: bits = box_row<RAD, 5>(ring, C, G, true); break;
 				case 6: bits = box_row<RAD, 6 % RING>(ring, C, G, true); break;
 				default: bits = box_row<RAD, 7 % RING>(ring, C, G, true); break;
 			}
-			if (K1_STORE == 0) {
-				if (((K1_ABLATE & 2) ? (bits == 0x12345u) : true) && t >= 2 * RAD && t < total) {
-					uint16_t* row16 = reinterpret_cast<uint16_t*>(out + (size_t)(y - RAD) * 32);
-					row16[lane ^ 1] = (uint16_t)bits;   // even lane = high half of word lane/2 (little-endian halves)
-				}
-			} else if (K1_STORE == 1) {
-				// word j = (lane 2j bits << 16) | lane 2j+1 bits; even lanes store one dword each
-				const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
-				if (t >= 2 * RAD && t < total && !(lane & 1)) out[(size_t)(y - RAD) * 32 + (lane >> 1)] = (bits << 16) | nb;
-			} else {
+			{
 				// gather the 8 x 16 bits of lanes 8k..8k+7 into lane 8k and store 16 bytes (columns 128k .. 128k+127 of the row)
 				const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xf, 0xf, true);   // lane^1
 				const uint32_t w0 = (lane & 1) ? ((nb << 16) | bits) : ((bits << 16) | nb);                        // word of lanes (2j,2j+1), in both

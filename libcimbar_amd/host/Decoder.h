@@ -1,0 +1,172 @@
+// cimbar_amd::Decoder -- C++ host adapter over the C ABI (include/cimbar_hip.h), mirroring the reference's frame-codec
+// surface for the decode_fountain path so that it drops in behind ./cimbar:
+//
+//     reference                                                  here
+//     ---------------------------------------------------------  ---------------------------------------------------
+//     class Decoder            src/lib/encoder/Decoder.h:16-38   cimbar_amd::Decoder           (same ctor / decode_fountain signature)
+//     STREAM concept           Decoder.h:171-189,                any type with chunk_size() and write(const char*, unsigned):
+//                              reed_solomon_stream.h:91-114      fountain_decoder_sink, concurrent_fountain_decoder_sink,
+//                                                                escrow_buffer_writer, null_stream -- used UNCHANGED
+//     class CimbReader         src/lib/cimb_translator/          cimbar_amd::CimbReader        (read / read_color / done / num_reads over the
+//                              CimbReader.h:13-41                                               GPU's per-cell results, linear cell order)
+//
+// Header-only; link against libcimbar_hip.so. No exceptions, no OpenCV requirement: MAT is anything shaped like cv::Mat
+// (`data`, `cols`, `rows`, `step`), e.g. cv::Mat, cv::UMat::getMat(), or cimbar_amd::image_view below.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/cimbar_hip.h"
+
+namespace cimbar_amd {
+
+// a borrowed RGB8 image, for callers without OpenCV
+struct image_view
+{
+	const unsigned char* data = nullptr;
+	int cols = 0;
+	int rows = 0;
+	size_t step = 0;   // bytes per row; 0 means cols*3
+};
+
+struct PositionData   // src/lib/cimb_translator/PositionData.h
+{
+	unsigned i = 0;
+	int x = 0;
+	int y = 0;
+};
+
+class Decoder
+{
+public:
+	// Decoder(use_ecc, interleave) as in Decoder.h:40-45. Only the reference's defaults (ECC on, interleave on, mode 68) exist on
+	// the GPU path; anything else leaves the object !good() and every decode returns 0, like a reference decode that found nothing.
+	explicit Decoder(bool use_ecc = true, bool interleave = true, int device = 0, int mode_val = 68)
+	{
+		if (use_ecc && interleave) _rc = cimbar_hip_create(device, mode_val, &_ctx);
+		else _rc = CIMBAR_HIP_EINVAL;
+	}
+	~Decoder() { if (_ctx) cimbar_hip_destroy(_ctx); }
+	Decoder(const Decoder&) = delete;
+	Decoder& operator=(const Decoder&) = delete;
+
+	bool good() const { return _ctx != nullptr; }
+	int error_code() const { return _rc; }
+	const char* last_error() const { return cimbar_hip_last_error(_ctx); }
+	cimbar_hip_ctx* context() { return _ctx; }
+
+	// Decoder::decode_fountain (Decoder.h:171-189): good chunks reach ostream.write(buf, 625) in chunk order, exactly what
+	// aligned_stream would have delivered; returns the cumulative good bytes. A sink whose chunk_size() is not 625 receives
+	// nothing but the byte count is still returned (Decoder.h:180-185).
+	template <typename MAT, typename FOUNTAINSTREAM>
+	unsigned decode_fountain(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess = false, int color_correction = 2)
+	{
+		if (!_ctx) return 0;
+		unsigned char chunks[CIMBAR_HIP_FRAME_BYTES];
+		uint32_t mask = 0;
+		const size_t step = image_step(img);
+		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
+		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
+		_rc = res < 0 ? res : 0;
+		if (res <= 0) return 0;   // CimbReader::_good == false / nothing decoded
+		if (ostream.chunk_size() == (unsigned)CIMBAR_HIP_CHUNK_SIZE)
+			for (int j = 0; j < CIMBAR_HIP_CHUNKS_PER_FRAME; ++j)
+				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * CIMBAR_HIP_CHUNK_SIZE, CIMBAR_HIP_CHUNK_SIZE);
+		return (unsigned)res;
+	}
+
+	// n densely packed 1024x1024 RGB8 frames in host memory, decoded on the GPU in one batch; chunks go to the sink in frame
+	// order then chunk order (what a single-threaded reference loop over the frames would have produced). Returns total good bytes.
+	template <typename FOUNTAINSTREAM>
+	unsigned long long decode_fountain_batch(const unsigned char* frames, int n, FOUNTAINSTREAM& ostream, bool should_preprocess = false,
+	                                         int color_correction = 2)
+	{
+		if (!_ctx || n <= 0) return 0;
+		_chunks.resize((size_t)n * CIMBAR_HIP_FRAME_BYTES);
+		_masks.resize((size_t)n);
+		int64_t res = cimbar_hip_decode_batch(_ctx, frames, n, CIMBAR_HIP_MEM_HOST, should_preprocess ? 1 : 0, color_correction,
+		                                      _chunks.data(), _masks.data(), CIMBAR_HIP_MEM_HOST, nullptr);
+		_rc = res < 0 ? (int)res : 0;
+		if (res <= 0) return 0;
+		if (ostream.chunk_size() == (unsigned)CIMBAR_HIP_CHUNK_SIZE)
+			for (int f = 0; f < n; ++f)
+				for (int j = 0; j < CIMBAR_HIP_CHUNKS_PER_FRAME; ++j)
+					if (_masks[f] & (1u << j))
+						ostream.write(reinterpret_cast<const char*>(_chunks.data()) + ((size_t)f * CIMBAR_HIP_CHUNKS_PER_FRAME + j) * CIMBAR_HIP_CHUNK_SIZE,
+						              CIMBAR_HIP_CHUNK_SIZE);
+		return (unsigned long long)res;
+	}
+
+	const std::vector<uint32_t>& last_masks() const { return _masks; }
+
+protected:
+	template <typename MAT>
+	static size_t image_step(const MAT& img)
+	{
+		size_t s = (size_t)img.step;
+		return s ? s : (size_t)img.cols * 3;
+	}
+
+	cimbar_hip_ctx* _ctx = nullptr;
+	int _rc = 0;
+	std::vector<unsigned char> _chunks;
+	std::vector<uint32_t> _masks;
+};
+
+// CimbReader's cell-level surface (CimbReader.h:13-41) over the GPU results of ONE frame. The frame is decoded at
+// construction; read() then walks the cells in linear index order (the reference walks them in flood order, but its caller
+// Decoder::do_decode places every result by pos.i, Decoder.h:84-97, so the order is not observable there) and returns the
+// 4 symbol bits plus the drifted position the colour pass used; read_color() returns the 2 colour bits of that cell.
+class CimbReader
+{
+public:
+	template <typename MAT>
+	CimbReader(const MAT& img, Decoder& decoder, bool needs_sharpen = false, int color_correction = 2)
+	{
+		unsigned char chunks[CIMBAR_HIP_FRAME_BYTES];
+		uint32_t mask = 0;
+		size_t step = (size_t)img.step ? (size_t)img.step : (size_t)img.cols * 3;
+		_good = decoder.good() && cimbar_hip_decode_frame(decoder.context(), reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols,
+		                                                  (unsigned)img.rows, step, needs_sharpen ? 1 : 0, color_correction, chunks, &mask) >= 0;
+		if (!_good) return;
+		_symbols.resize(CIMBAR_HIP_CELLS);
+		_colors.resize(CIMBAR_HIP_CELLS);
+		_drift.resize((size_t)CIMBAR_HIP_CELLS * 2);
+		_good = cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_SYMBOLS, _symbols.data(), _symbols.size()) >= 0 &&
+		        cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_COLORS, _colors.data(), _colors.size()) >= 0 &&
+		        cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_DRIFT, _drift.data(), _drift.size()) >= 0;
+	}
+
+	unsigned read(PositionData& pos)
+	{
+		if (done()) return 0;
+		const unsigned i = _next++;
+		int x, y;
+		cell_xy(i, x, y);
+		pos.i = i;
+		pos.x = x + _drift[2 * i];
+		pos.y = y + _drift[2 * i + 1];
+		return _symbols[i];
+	}
+	unsigned read_color(const PositionData& pos) const { return pos.i < _colors.size() ? _colors[pos.i] : 0; }
+	bool done() const { return !_good || _next >= (unsigned)CIMBAR_HIP_CELLS; }
+	unsigned num_reads() const { return CIMBAR_HIP_CELLS; }
+
+	// CellPositions::compute_linear for Conf8x8 (CellPositions.cpp:5-51)
+	static void cell_xy(unsigned i, int& x, int& y)
+	{
+		if (i < 600) { x = 62 + (int)(i % 100) * 9; y = 8 + (int)(i / 100) * 9; }
+		else if (i < 11800) { unsigned j = i - 600; x = 8 + (int)(j % 112) * 9; y = 62 + (int)(j / 112) * 9; }
+		else { unsigned j = i - 11800; x = 62 + (int)(j % 100) * 9; y = 962 + (int)(j / 100) * 9; }
+	}
+
+protected:
+	bool _good = false;
+	unsigned _next = 0;
+	std::vector<unsigned char> _symbols, _colors;
+	std::vector<signed char> _drift;
+};
+
+}  // namespace cimbar_amd

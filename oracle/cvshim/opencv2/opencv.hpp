@@ -401,28 +401,48 @@ inline void adaptiveThreshold(const Mat& src_, Mat& dst, double maxval, int, int
 	scalef -= divScale;
 	int divDelta = d / 2;
 	if (scalef < 0.5) divDelta++; else divScale++;
-	int idelta = (int)std::ceil(C);
-	auto clampi = [](int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); };
-	std::vector<int> rowsum((size_t)src.rows * src.cols);
-	for (int y = 0; y < src.rows; ++y)
+	const int idelta = (int)std::ceil(C);
+	const uchar on = saturate_u8(cvRound(maxval));
+	const int W = src.cols, H = src.rows;
+	// separable box sum with running windows (what OpenCV's RowSum/ColumnSum do), BORDER_REPLICATE on both axes
+	std::vector<uint16_t> rowsum((size_t)W * H);
+	for (int y = 0; y < H; ++y)
 	{
 		const uchar* s = src.ptr<uchar>(y);
-		for (int x = 0; x < src.cols; ++x)
+		uint16_t* o = rowsum.data() + (size_t)y * W;
+		int acc = 0;
+		for (int k = -r; k <= r; ++k) acc += s[k < 0 ? 0 : (k >= W ? W - 1 : k)];
+		o[0] = (uint16_t)acc;
+		for (int x = 1; x < W; ++x)
 		{
-			int acc = 0;
-			for (int k = -r; k <= r; ++k) acc += s[clampi(x + k, src.cols)];
-			rowsum[(size_t)y * src.cols + x] = acc;
+			int xin = x + r, xout = x - r - 1;
+			acc += s[xin >= W ? W - 1 : xin] - s[xout < 0 ? 0 : xout];
+			o[x] = (uint16_t)acc;
 		}
 	}
-	for (int y = 0; y < src.rows; ++y)
-		for (int x = 0; x < src.cols; ++x)
+	std::vector<int> col((size_t)W, 0);
+	for (int k = -r; k <= r; ++k)
+	{
+		const uint16_t* rs = rowsum.data() + (size_t)(k < 0 ? 0 : (k >= H ? H - 1 : k)) * W;
+		for (int x = 0; x < W; ++x) col[x] += rs[x];
+	}
+	for (int y = 0; y < H; ++y)
+	{
+		if (y > 0)
 		{
-			int acc = 0;
-			for (int k = -r; k <= r; ++k) acc += rowsum[(size_t)clampi(y + k, src.rows) * src.cols + x];
-			int mean = (int)(((unsigned)(acc + divDelta) * (unsigned)divScale) >> SHIFT);
-			int v = src.ptr<uchar>(y)[x];
-			out.ptr<uchar>(y)[x] = (v - mean > -idelta) ? saturate_u8(cvRound(maxval)) : 0;
+			int yin = y + r, yout = y - r - 1;
+			const uint16_t* rin = rowsum.data() + (size_t)(yin >= H ? H - 1 : yin) * W;
+			const uint16_t* rout = rowsum.data() + (size_t)(yout < 0 ? 0 : yout) * W;
+			for (int x = 0; x < W; ++x) col[x] += rin[x] - rout[x];
 		}
+		const uchar* s = src.ptr<uchar>(y);
+		uchar* o = out.ptr<uchar>(y);
+		for (int x = 0; x < W; ++x)
+		{
+			int mean = (int)(((unsigned)(col[x] + divDelta) * (unsigned)divScale) >> SHIFT);
+			o[x] = ((int)s[x] - mean > -idelta) ? on : 0;
+		}
+	}
 	dst = out;
 }
 

@@ -7,8 +7,11 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr size_t FRAME = 1024ull * 1024 * 3;
 
+#ifndef WPE
+#define WPE 8
+#endif
 template <int MODE, int DEPTH, int ROWS>
-__global__ __launch_bounds__(256) void k_stream(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ out, int strips)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_stream(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ out, int strips)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int strip = blockIdx.x * 4 + wave;
