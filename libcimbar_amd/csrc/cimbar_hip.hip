@@ -13,7 +13,7 @@
 //   K4 k_frame_mid      aligned_stream bookkeeping for the symbol chunks, fountain-header prediction, CCM derivation
 //   K5 k_colors         6x6 cell mean -> CCM -> palette classifier
 //   K3 k_rs             (colours: 20 blocks)
-//   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots
+//   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots, CCM carry-out
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -217,7 +217,8 @@ template <int RAD, bool PRE>
 #define K1_WAVES 3
 #endif
 __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
-                                                                uint32_t* __restrict__ cellmean, int f0)
+                                                                uint32_t* __restrict__ cellmean, uint32_t* __restrict__ flood_flag,
+                                                                unsigned long long* __restrict__ total_good, int f0)
 {
 	constexpr int RING = 2 * RAD + 2;
 	__shared__ __attribute__((aligned(16))) uint16_t s_col[4][IMG * 3];   // per-wave column sums of one cell row, by row byte
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 	const int y_begin = strip == 0 ? 0 : OFFSET + strip * K1_CELLROWS * PITCH;
 	const int y_end = strip == K1_STRIPS - 1 ? IMG : OFFSET + (strip + 1) * K1_CELLROWS * PITCH;
 	const int total = (y_end - y_begin) + 2 * RAD;
+	if (strip == 0 && lane == 0) {   // per-batch state the later kernels accumulate into
+		flood_flag[f] = 0;
+		if (blockIdx.y == 0) *total_good = 0;
+	}
 
 	uint32_t ring[RING][8];
 	uint32_t C[8];
@@ -400,6 +405,16 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 	return v;
 }
 
+// Exact-match shortcut: on clean frames ~99 % of the centre hashes ARE one of the 16 tile hashes. A 5-bit perfect hash of
+// the 64-bit value ((lo ^ hi) * 0x61b91 >> 27 is collision-free over the 16 tiles) names the only tile it could be; one
+// 64-bit compare confirms distance 0. Anything else takes the full popcount match below.
+__constant__ uint8_t c_tile_slot[32] = {16, 9, 13, 16, 1, 0, 16, 16, 8, 2, 3, 16, 16, 7, 16, 16, 16, 16, 6, 12, 16, 16, 11, 16, 10, 5, 16, 4, 15, 16, 16, 14};
+__device__ __forceinline__ uint32_t exact_tile(uint64_t h)
+{
+	const uint32_t slot = c_tile_slot[(((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x61b91u) >> 27];
+	return (slot < 16 && c_tile[slot] == h) ? slot : 16u;
+}
+
 // K2: every cell evaluated at drift (0,0). If, for every cell, no shifted window beats the centre one (4 side windows
 // for ordinary cells, all 8 for the flood seeds, which may be popped in 9-window mode), the reference's flood visits
 // every cell at drift (0,0) with cooldown 4|0xFE whatever its heap order, so symbol = argmin_tile popcnt(centre ^ tile)
@@ -407,52 +422,99 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 // One lane per cell for the centre match (the common case ends there: distance 0). The few cells with a non-zero centre
 // distance are then re-examined one at a time by the whole wave: their window rows are broadcast, the 4 (+4) shifted
 // hashes are formed once on uniform data and the 64 lanes split the (window, tile) pairs.
+// 10x10 window rows out of an LDS copy of the bit rows (32 words per row)
+__device__ __forceinline__ void window_rows_lds(const uint32_t* rows32, int x0, uint32_t rows[10])
+{
+	const int j = x0 >> 5, sh = 54 - (x0 & 31);
+	const int j1 = j + 1 > 31 ? 31 : j + 1;
+#pragma unroll
+	for (int i = 0; i < 10; ++i) {
+		const uint32_t* r = rows32 + i * 32;
+		uint64_t v = ((uint64_t)r[j] << 32) | r[j1];
+		rows[i] = (uint32_t)(v >> sh) & 0x3FFu;
+	}
+}
+
+// linear cell index of grid cell (row, col), or -1 inside the corner cut-outs (CellPositions.cpp:5-51)
+__device__ __forceinline__ int cell_index(int row, int col)
+{
+	const bool margin = row < MARKER || row >= DIM - MARKER;
+	if (margin && (col < MARKER || col >= DIM - MARKER)) return -1;
+	if (row < MARKER) return row * TOP_W + (col - MARKER);
+	if (row < DIM - MARKER) return TOP_CELLS + (row - MARKER) * DIM + col;
+	return TOP_CELLS + MID_CELLS + (row - (DIM - MARKER)) * TOP_W + (col - MARKER);
+}
+
+// One workgroup per 16 cell rows: the 145 bit rows they touch (18.6 KB) are staged in LDS with coalesced loads, then the
+// block walks the rows two at a time and every lane cuts its 10x10 window out of LDS. Few, fat waves on purpose: with one
+// short wave per 64 cells the kernel was bound by the workgroup dispatch rate, not by memory or ALU.
+constexpr int K2_ROWS = 2, K2_BLOCK_ROWS = 16;
 __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ plane, Tables tb, uint8_t* __restrict__ symbols,
                                                  uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag, int f0)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
+	__shared__ uint32_t s_rows[(K2_BLOCK_ROWS * PITCH + 1) * 32];
 	const int f = f0 + blockIdx.y;
 	const int lane = threadIdx.x & 63;
-	const bool live = i < NCELLS;
-	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
-	uint32_t rows[10];
-	uint32_t dc = 0;
-	if (live) {
-		ushort2 xy = tb.cell_xy[i];
-		window_rows(pl, (int)xy.x - 1, (int)xy.y - 1, rows);
-		const uint32_t centre = best_tile(window_hash(rows, 4));
-		dc = centre >> 4;
-		symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
-		if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
-	} else {
-#pragma unroll
-		for (int k = 0; k < 10; ++k) rows[k] = 0;
-	}
+	const int brow0 = blockIdx.x * K2_BLOCK_ROWS;
+	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS + (size_t)(OFFSET + brow0 * PITCH - 1) * 32;   // first bit row needed: y0 - 1
+	for (int k = threadIdx.x; k < (K2_BLOCK_ROWS * PITCH + 1) * 32; k += 256) s_rows[k] = pl[k];
+	__syncthreads();
 
-	unsigned long long todo = __ballot(live && dc != 0);
-	if (todo == 0) return;
+	const int rsel = threadIdx.x / DIM, col = threadIdx.x % DIM;
 	const uint64_t my_tile = c_tile[lane & 15];
 	const int grp = lane >> 4;
 	bool shifted = false;
-	while (todo) {
-		const int L = __builtin_ctzll(todo);
-		todo &= todo - 1;
-		uint32_t ur[10];
+	for (int it = 0; it < K2_BLOCK_ROWS / K2_ROWS; ++it) {
+		const int row = brow0 + it * K2_ROWS + rsel;
+		const int i = rsel < K2_ROWS ? cell_index(row, col) : -1;
+		const bool live = i >= 0;
+		uint32_t rows[10];
+		uint32_t dc = 0;
+		uint64_t hc = 0;
+		uint32_t sym = 16;
+		if (live) {
+			window_rows_lds(s_rows + (it * K2_ROWS + rsel) * PITCH * 32, OFFSET + col * PITCH - 1, rows);
+			hc = window_hash(rows, 4);
+			sym = exact_tile(hc);
+		} else {
 #pragma unroll
-		for (int k = 0; k < 10; ++k) ur[k] = (uint32_t)__builtin_amdgcn_readlane((int)rows[k], L);
-		const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dc, L);
-		const int cell = blockIdx.x * 256 + (threadIdx.x & ~63) + L;
-		// side windows 5,7,3,1 on lane groups 0..3 (uniform hashes, per-lane select)
-		const uint64_t h5 = window_hash(ur, 5), h7 = window_hash(ur, 7), h3 = window_hash(ur, 3), h1 = window_hash(ur, 1);
-		uint64_t h = grp == 0 ? h5 : (grp == 1 ? h7 : (grp == 2 ? h3 : h1));
-		uint32_t best = (uint32_t)__popcll(h ^ my_tile);
-		if (is_seed(cell)) {
-			const uint64_t h8 = window_hash(ur, 8), h0 = window_hash(ur, 0), h2 = window_hash(ur, 2), h6 = window_hash(ur, 6);
-			h = grp == 0 ? h8 : (grp == 1 ? h0 : (grp == 2 ? h2 : h6));
-			const uint32_t d2 = (uint32_t)__popcll(h ^ my_tile);
-			best = d2 < best ? d2 : best;
+			for (int k = 0; k < 10; ++k) rows[k] = 0;
 		}
-		if (wave_min(best) < dL) shifted = true;
+		// lanes whose centre hash is not an exact tile: full 16-tile popcount match (wave-uniform branch: skipped entirely
+		// for the waves of a clean frame where every cell matched exactly)
+		if (__any(live && sym == 16)) {
+			if (live && sym == 16) {
+				const uint32_t centre = best_tile(hc);
+				dc = centre >> 4;
+				sym = centre & 15u;
+			}
+		}
+		if (live) {
+			symbols[(size_t)f * NCELLS + i] = (uint8_t)sym;
+			if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
+		}
+
+		unsigned long long todo = __ballot(live && dc != 0);
+		while (todo) {
+			const int L = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			uint32_t ur[10];
+#pragma unroll
+			for (int k = 0; k < 10; ++k) ur[k] = (uint32_t)__builtin_amdgcn_readlane((int)rows[k], L);
+			const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dc, L);
+			const int cell = __builtin_amdgcn_readlane(i, L);
+			// side windows 5,7,3,1 on lane groups 0..3 (uniform hashes, per-lane select)
+			const uint64_t h5 = window_hash(ur, 5), h7 = window_hash(ur, 7), h3 = window_hash(ur, 3), h1 = window_hash(ur, 1);
+			uint64_t h = grp == 0 ? h5 : (grp == 1 ? h7 : (grp == 2 ? h3 : h1));
+			uint32_t best = (uint32_t)__popcll(h ^ my_tile);
+			if (is_seed(cell)) {
+				const uint64_t h8 = window_hash(ur, 8), h0 = window_hash(ur, 0), h2 = window_hash(ur, 2), h6 = window_hash(ur, 6);
+				h = grp == 0 ? h8 : (grp == 1 ? h0 : (grp == 2 ? h2 : h6));
+				const uint32_t d2 = (uint32_t)__popcll(h ^ my_tile);
+				best = d2 < best ? d2 : best;
+			}
+			if (wave_min(best) < dL) shifted = true;
+		}
 	}
 	if (shifted && lane == 0) atomicOr(&flood_flag[f], 1u);
 }
@@ -1077,7 +1139,10 @@ __device__ __forceinline__ uint32_t best_color(float r, float g, float b, const 
 	float mx = r; if (g > mx) mx = g; if (b > mx) mx = b; if (1.0f > mx) mx = 1.0f;
 	float mn = r; if (g < mn) mn = g; if (b < mn) mn = b; if (48.0f < mn) mn = 48.0f;
 	if (mn >= mx) mn = 0;
-	float adjust = (float)(255.0 / (double)(mx - mn));
+	// the reference computes 255.0/(max-min) in double and narrows to float (CimbDecoder.cpp:180). With both operands
+	// exactly representable in binary32, double rounding through binary64 (53 >= 2*24+2 bits) is innocuous for division,
+	// so the correctly rounded binary32 quotient is the same number -- and costs a third of the fp64 divide here.
+	float adjust = __fdiv_rn(255.0f, mx - mn);
 	int c0 = (int)fix_single_color(r, adjust, mn), c1 = (int)fix_single_color(g, adjust, mn), c2 = (int)fix_single_color(b, adjust, mn);
 	int rel0 = c0 - c1, rel1 = c1 - c2, rel2 = c2 - c0;
 	uint32_t best_fit = 0, best_distance = 1000000u;
@@ -1105,11 +1170,16 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 	__shared__ int s_have_hdr;
 	__shared__ uint32_t s_cnt[4], s_r[4], s_g[4], s_b[4], s_first[4];
 
+	// one load per lane instead of 40 + 6 dependent ones on lane 0: RS flags -> ballot, chunk headers -> LDS
+	__shared__ uint8_t s_chunk_hdr[8 * CHUNK];   // only bytes [j*625, j*625+6) are filled / read (aligner_block's indexing)
+	const unsigned long long ok_bits = __ballot(lane < SYM_BLOCKS && rs_ok[(size_t)f * ALL_BLOCKS + (lane < SYM_BLOCKS ? lane : 0)] != 0);
+	if (lane < 48) s_chunk_hdr[(lane / 6) * CHUNK + lane % 6] = fc[(size_t)(lane / 6) * CHUNK + lane % 6];
+	__syncthreads();
 	if (lane == 0) {
 		FrameState st = {0, 0, 0, 0};
 		uint8_t hdr[6] = {0, 0, 0, 0, 0, 0};
 		unsigned radio = 0;
-		for (int b = 0; b < SYM_BLOCKS; ++b) aligner_block(st, b, rs_ok[(size_t)f * ALL_BLOCKS + b], fc, true, hdr, radio);
+		for (int b = 0; b < SYM_BLOCKS; ++b) aligner_block(st, b, (int)((ok_bits >> b) & 1ull), s_chunk_hdr, true, hdr, radio);
 		states[f] = st;
 		s_have_hdr = md_id(hdr) != 0;
 		for (int c = 0; c < 4; ++c) {
@@ -1182,6 +1252,7 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 	}
 }
 
+constexpr int K5_CELLS = 7;   // 7 * 256 = 1792 cells per workgroup -> 7 workgroups per frame
 // K5: colour pass (Decoder.h:107-113; CimbReader.cpp:133-137; CimbDecoder.cpp:202-217). The matrix in force for frame
 // f is the newest valid one among frames <= f of this batch, else the context's carried one (slot `carry`).
 __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ cellmean, Tables tb,
@@ -1200,34 +1271,54 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 		if (blockIdx.x == 0) for (int k = 0; k < 10; ++k) ccm_used[(size_t)f * 10 + k] = src[k];
 	}
 	__syncthreads();
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= NCELLS) return;
-	ushort2 xy = tb.cell_xy[i];
-	int x = (int)xy.x, y = (int)xy.y;
-	uint32_t col[3];
-	if (flood_flag[f]) {
-		// the frame went through the exact flood pass: cells are read where their drift put them
-		x += drift[((size_t)f * NCELLS + i) * 2]; y += drift[((size_t)f * NCELLS + i) * 2 + 1];
-		mean6x6(rgb + (size_t)f * FRAME_RGB, x + 1, y + 1, col);
-	} else {
-		const uint32_t mv = cellmean[(size_t)f * GRID_CELLS + ((y - OFFSET) / PITCH) * DIM + (x - OFFSET) / PITCH];
-		col[0] = mv & 0xFFu; col[1] = (mv >> 8) & 0xFFu; col[2] = (mv >> 16) & 0xFFu;
+	const bool flooded = flood_flag[f] != 0;
+	const bool active = s_m[9] != 0.0f;
+	// few, fat waves (the kernel is otherwise bound by the workgroup dispatch rate): K5_CELLS cells per lane
+	uint32_t mv[K5_CELLS];
+	if (!flooded) {   // all of a lane's loads go out before the first classifier runs
+#pragma unroll
+		for (int k = 0; k < K5_CELLS; ++k) {
+			const int i = (blockIdx.x * K5_CELLS + k) * 256 + threadIdx.x;
+			mv[k] = 0;
+			if (i < NCELLS) {
+				ushort2 xy = tb.cell_xy[i];
+				mv[k] = cellmean[(size_t)f * GRID_CELLS + (((int)xy.y - OFFSET) / PITCH) * DIM + ((int)xy.x - OFFSET) / PITCH];
+			}
+		}
 	}
-	colors[(size_t)f * NCELLS + i] = (uint8_t)best_color((float)col[0], (float)col[1], (float)col[2], s_m, s_m[9] != 0.0f);
+#pragma unroll
+	for (int k = 0; k < K5_CELLS; ++k) {
+		const int i = (blockIdx.x * K5_CELLS + k) * 256 + threadIdx.x;
+		if (i >= NCELLS) break;
+		uint32_t col[3];
+		if (flooded) {
+			// the frame went through the exact flood pass: cells are read where their drift put them
+			ushort2 xy = tb.cell_xy[i];
+			const int x = (int)xy.x + drift[((size_t)f * NCELLS + i) * 2], y = (int)xy.y + drift[((size_t)f * NCELLS + i) * 2 + 1];
+			mean6x6(rgb + (size_t)f * FRAME_RGB, x + 1, y + 1, col);
+		} else {
+			col[0] = mv[k] & 0xFFu; col[1] = (mv[k] >> 8) & 0xFFu; col[2] = (mv[k] >> 16) & 0xFFu;
+		}
+		colors[(size_t)f * NCELLS + i] = (uint8_t)best_color((float)col[0], (float)col[1], (float)col[2], s_m, active);
+	}
 }
 
 // K7: chunk bookkeeping for the colour blocks, final mask, zero the slots of dropped chunks, per-frame good bytes
 __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
                                                   uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
-                                                  unsigned long long* __restrict__ total_good, int f0)
+                                                  unsigned long long* __restrict__ total_good, const float* __restrict__ ccm_used,
+                                                  float* __restrict__ carry, int f0)
 {
 	const int f = f0 + blockIdx.x, lane = threadIdx.x;
+	// the matrix carried into the next call = the one in force for the batch's last frame (CimbDecoder.cpp:69-85)
+	if (blockIdx.x == gridDim.x - 1 && lane < 10) carry[lane] = ccm_used[(size_t)f * 10 + lane];
 	__shared__ uint32_t s_mask;
+	const unsigned long long ok_bits = __ballot(lane < COL_BLOCKS && rs_ok[(size_t)f * ALL_BLOCKS + SYM_BLOCKS + (lane < COL_BLOCKS ? lane : 0)] != 0);
 	if (lane == 0) {
 		FrameState st = states[f];
 		uint8_t hdr[6] = {0, 0, 0, 0, 0, 0};
 		unsigned radio = 0;
-		for (int b = 0; b < COL_BLOCKS; ++b) aligner_block(st, SYM_BLOCKS + b, rs_ok[(size_t)f * ALL_BLOCKS + SYM_BLOCKS + b], nullptr, false, hdr, radio);
+		for (int b = 0; b < COL_BLOCKS; ++b) aligner_block(st, SYM_BLOCKS + b, (int)((ok_bits >> b) & 1ull), nullptr, false, hdr, radio);
 		states[f] = st;
 		masks[f] = st.mask;
 		s_mask = st.mask;
@@ -1239,12 +1330,6 @@ __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs
 	for (int j = 0; j < CHUNKS; ++j)
 		if (!(mask & (1u << j)))
 			for (int k = lane; k < CHUNK; k += 64) fc[(size_t)j * CHUNK + k] = 0;
-}
-
-// carried CCM after the batch = the matrix in force for its last frame
-__global__ void k_ccm_carry(const float* __restrict__ ccm_used, int last, float* __restrict__ carry)
-{
-	if (threadIdx.x < 10) carry[threadIdx.x] = ccm_used[(size_t)last * 10 + threadIdx.x];
 }
 
 // repack the internal word-oriented bitplane into CimbReader::_grayscale's byte layout (tap only)
@@ -1288,14 +1373,14 @@ struct cimbar_hip_ctx {
 	int flood_cap = 0;
 	// timing
 	bool timing = false;
-	static constexpr int NSTAGE = 9;
+	static constexpr int NSTAGE = 8;
 	hipEvent_t ev[NSTAGE + 1] = {};
 	float stage_ms[NSTAGE] = {};
 };
 
 namespace {
 
-const char* const STAGE_NAMES[cimbar_hip_ctx::NSTAGE] = {"threshold", "symbols", "flood", "rs_symbols", "frame_mid", "colors", "rs_colors", "frame_end", "ccm_carry"};
+const char* const STAGE_NAMES[cimbar_hip_ctx::NSTAGE] = {"threshold", "symbols", "flood", "rs_symbols", "frame_mid", "colors", "rs_colors", "frame_end"};
 
 #define HIPCHK(call)                                                                                      \
 	do {                                                                                                  \
@@ -1452,16 +1537,14 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	const dim3 cell_grid((NCELLS + 255) / 256, n);
 	const int f0 = 0;   // kernels index frames as f0 + block index, so a caller may also run a sub-range of a resident batch
 
-	HIPCHK(hipMemsetAsync(ctx->d_flood, 0, sizeof(uint32_t) * (size_t)n, st));
-	HIPCHK(hipMemsetAsync(ctx->d_total, 0, sizeof(unsigned long long), st));
 	HIPCHK(mark());
 	{
 		dim3 g(K1_STRIPS / 4, n);
-		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, f0);
-		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, f0);
+		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, ctx->d_total, f0);
+		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, ctx->d_total, f0);
 	}
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_symbols, cell_grid, dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
+	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_flood, dim3(n), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols, ctx->d_drift, ctx->d_dist, f0);
 	HIPCHK(mark());
@@ -1469,13 +1552,11 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_colors, cell_grid, dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used, f0);
+	hipLaunchKernelGGL(k_colors, dim3((NCELLS + 256 * K5_CELLS - 1) / (256 * K5_CELLS), n), dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used, f0);
 	HIPCHK(mark());
 	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, f0, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total, f0);
-	HIPCHK(mark());
-	hipLaunchKernelGGL(k_ccm_carry, dim3(1), dim3(64), 0, st, ctx->d_ccm_used, n - 1, ctx->d_carry);
+	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total, ctx->d_ccm_used, ctx->d_carry, f0);
 	HIPCHK(mark());
 	HIPCHK(hipGetLastError());
 	ctx->last_n = n;

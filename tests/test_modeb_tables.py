@@ -32,3 +32,13 @@ def test_synth_payload_headers():
     assert (p[:, 0] == 9).all() and ((p[:, 1].astype(int) << 16) + (p[:, 2].astype(int) << 8) + p[:, 3] == 70000).all()
     ids = (p[:, 4].astype(int) << 8) + p[:, 5]
     assert list(ids[:8]) == [65530, 65531, 65532, 65533, 65534, 65535, 0, 1]
+
+
+def test_classifier_division_can_be_done_in_float32():
+    # CimbDecoder.cpp:180 divides in double and narrows; the HIP classifier divides in binary32. Double rounding
+    # through binary64 is innocuous for a quotient of two binary32 numbers -- spot-check a few million denominators.
+    g = np.random.default_rng(0)
+    d = np.concatenate([np.arange(1, 256, dtype=np.float32), g.uniform(1e-3, 300, 2_000_000).astype(np.float32)])
+    a = (np.float64(255.0) / d.astype(np.float64)).astype(np.float32)
+    b = np.float32(255.0) / d
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
