@@ -67,9 +67,10 @@ int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
 /* The same for `n` independent frames, decoded in frame order (frame f's CCM carry-over sees frames < f).
  *   rgb        : n densely packed 1024*1024*3 frames, in host or device memory (rgb_mem)
  *   chunks     : n*7500 bytes, masks: n words, in host or device memory (out_mem)
- *   hip_stream : a hipStream_t to enqueue on (NULL = the context's own stream). With device outputs the call only
- *                enqueues work and returns 0; the caller synchronises the stream. With host outputs it synchronises
- *                and returns the total good bytes over the batch (may exceed INT_MAX only beyond 286k frames).
+ *   hip_stream : a hipStream_t to enqueue on. NULL = the null stream when a device buffer is involved (ordinary HIP
+ *                semantics: ordered after the work that produced the frames there), the context's own stream when
+ *                everything is host memory. With device outputs the call only enqueues work and returns 0; the caller
+ *                synchronises the stream. With host outputs it synchronises and returns the total good bytes over the batch.
  */
 int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
                                 int color_correction, uint8_t* chunks, uint32_t* masks, int out_mem, void* hip_stream);

@@ -1624,7 +1624,10 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	if (!rgb || !chunks || !masks || n <= 0) { ctx->err = "decode_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
 	HIPCHK(hipSetDevice(ctx->device));
-	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	// NULL means what it means for any HIP launch -- the (legacy) null stream -- whenever a device buffer is involved, so the
+	// work is ordered after whatever produced the frames there; the all-host path synchronises anyway and uses its own stream
+	const bool any_device = rgb_mem == CIMBAR_HIP_MEM_DEVICE || out_mem == CIMBAR_HIP_MEM_DEVICE;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
 	if (int r = ensure_capacity(ctx, n)) return r;
 
 	const uint8_t* d_rgb = rgb;

@@ -134,7 +134,8 @@ class HipDecoder:
 
     # ------------------------------------------------------------------ device-memory entry point (torch tensors as raw memory)
     def decode_batch_device(self, frames_ptr, n, chunks_ptr, masks_ptr, should_preprocess=False, color_correction=2, stream=None):
-        """Enqueue a batch whose input and outputs are device pointers (ints). Asynchronous: caller synchronises `stream`."""
+        """Enqueue a batch whose input and outputs are device pointers (ints) on HIP stream handle `stream` (None / 0 = the null
+        stream, i.e. torch's default stream). Asynchronous: the caller synchronises that stream."""
         rc = self._lib.cimbar_hip_decode_batch(self._ctx, ctypes.c_void_p(frames_ptr), int(n), MEM_DEVICE,
                                                int(bool(should_preprocess)), int(color_correction), ctypes.c_void_p(chunks_ptr),
                                                ctypes.c_void_p(masks_ptr), MEM_DEVICE,
