@@ -1,0 +1,52 @@
+"""GPU, BASELINE configs[3] in miniature on one device: a real wirehair fountain stream of a file is rendered into frames,
+decoded in slabs (as the ranks of an 8-GPU job would), the chunk slots are concatenated in rank order and fed to ONE reference
+fountain_decoder_sink, which must reassemble the file."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import framegen, modeb, multigpu
+from oracle import pyref
+from oracle.pyref import P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fountain_stream_through_sharded_decode_and_single_sink(hip_decoder, ref):
+    dev = torch.device("cuda", 0)
+    data = np.random.default_rng(4321).integers(0, 256, 1 << 20, dtype=np.uint8)       # 1 MiB file -> 1695 wirehair blocks
+    n_frames, world = 160, 8
+    chunks_in = np.zeros((n_frames * 12, 625), np.uint8)
+    assert ref.ref_fountain_chunks(P(data), data.size, 9, n_frames * 12, P(chunks_in)) == n_frames * 12
+    payload = torch.from_numpy(chunks_in.reshape(n_frames, 7500)).to(dev)
+    synth = framegen.FrameSynth(dev)
+
+    outs, masks_all = [], []
+    for rank in range(world):                                   # what rank `rank` of an 8-GPU job would do
+        lo, hi, per = multigpu.shard_range(n_frames, rank, world)
+        frames = synth.frames_from_payload(payload[lo:hi])
+        c = torch.zeros((per, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
+        m = torch.zeros((per,), dtype=torch.int32, device=dev)
+        dec = hip_decoder
+        dec.reset_ccm()                                         # every rank starts with a fresh decoder
+        dec.decode_batch_device(frames.data_ptr(), hi - lo, c.data_ptr(), m.data_ptr(), False, 2, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(c)
+        masks_all.append(m)
+    all_chunks, all_masks = torch.cat(outs, 0), torch.cat(masks_all, 0)     # == gather to rank 0 in rank order
+    assert bool((all_chunks[:n_frames] == payload).all())
+
+    ref.ref_sink_reset(625)
+    out = np.zeros(data.size, np.uint8)
+    done = []
+
+    def on_complete(file_id):
+        assert ref.ref_sink_recover(ctypes.c_uint32(file_id), P(out), out.size) == 1
+        done.append(file_id)
+    res = multigpu.feed_sink(lambda c: ref.ref_sink_decode_frame(P(np.ascontiguousarray(c)), 625), all_chunks, all_masks, on_complete)
+    assert len(done) == 1, res[:10]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()
+    assert sum(1 for r in res if r == -1) > 0          # chunks after completion are ignored (fountain_decoder_sink.h:146-148)
