@@ -397,14 +397,6 @@ __device__ __forceinline__ bool is_seed(int i)
 	       i == NCELLS - 1 - TOP_CELLS || i == NCELLS - TOP_CELLS - DIM;
 }
 
-// minimum of a 32-bit value over the wave (ds_bpermute butterflies; used only on the rare slow path)
-__device__ __forceinline__ uint32_t wave_min(uint32_t v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = o < v ? o : v; }
-	return v;
-}
-
 // Exact-match shortcut: on clean frames ~99 % of the centre hashes ARE one of the 16 tile hashes. A 5-bit perfect hash of
 // the 64-bit value ((lo ^ hi) * 0x61b91 >> 27 is collision-free over the 16 tiles) names the only tile it could be; one
 // 64-bit compare confirms distance 0. Anything else takes the full popcount match below.
@@ -445,78 +437,79 @@ __device__ __forceinline__ int cell_index(int row, int col)
 	return TOP_CELLS + MID_CELLS + (row - (DIM - MARKER)) * TOP_W + (col - MARKER);
 }
 
-// One workgroup per 16 cell rows: the 145 bit rows they touch (18.6 KB) are staged in LDS with coalesced loads, then the
-// block walks the rows two at a time and every lane cuts its 10x10 window out of LDS. Few, fat waves on purpose: with one
-// short wave per 64 cells the kernel was bound by the workgroup dispatch rate, not by memory or ALU.
-constexpr int K2_ROWS = 2, K2_BLOCK_ROWS = 16;
+// One workgroup per 16 cell rows: the 145 bit rows they touch (18.6 KB) are staged in LDS with coalesced loads. Few, fat
+// waves on purpose: with one short wave per 64 cells the kernel was bound by the workgroup dispatch rate.
+// Phase 1 (every cell, cheap): centre hash from 8 bit rows, exact-match shortcut; a cell that is not an exact tile is queued.
+// Phase 2 (queued cells only, ~1 % on clean frames, all of them on noisy ones): the full popcount match of the centre and,
+// if its distance is not 0, of the 4 (seeds: 8) shifted windows -- one lane per queued cell, so the rare work is compacted
+// into a few lanes instead of stalling every wave.
+constexpr int K2_BLOCK_ROWS = 16, K2_CELLS = K2_BLOCK_ROWS * DIM;   // 1792 cells per workgroup
 __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ plane, Tables tb, uint8_t* __restrict__ symbols,
                                                  uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag, int f0)
 {
 	__shared__ uint32_t s_rows[(K2_BLOCK_ROWS * PITCH + 1) * 32];
+	__shared__ uint16_t s_queue[K2_CELLS];
+	__shared__ int s_qn;
 	const int f = f0 + blockIdx.y;
-	const int lane = threadIdx.x & 63;
 	const int brow0 = blockIdx.x * K2_BLOCK_ROWS;
 	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS + (size_t)(OFFSET + brow0 * PITCH - 1) * 32;   // first bit row needed: y0 - 1
+	if (threadIdx.x == 0) s_qn = 0;
 	for (int k = threadIdx.x; k < (K2_BLOCK_ROWS * PITCH + 1) * 32; k += 256) s_rows[k] = pl[k];
 	__syncthreads();
 
-	const int rsel = threadIdx.x / DIM, col = threadIdx.x % DIM;
-	const uint64_t my_tile = c_tile[lane & 15];
-	const int grp = lane >> 4;
-	bool shifted = false;
-	for (int it = 0; it < K2_BLOCK_ROWS / K2_ROWS; ++it) {
-		const int row = brow0 + it * K2_ROWS + rsel;
-		const int i = rsel < K2_ROWS ? cell_index(row, col) : -1;
-		const bool live = i >= 0;
-		uint32_t rows[10];
-		uint32_t dc = 0;
-		uint64_t hc = 0;
-		uint32_t sym = 16;
-		if (live) {
-			window_rows_lds(s_rows + (it * K2_ROWS + rsel) * PITCH * 32, OFFSET + col * PITCH - 1, rows);
-			hc = window_hash(rows, 4);
-			sym = exact_tile(hc);
-		} else {
+	for (int lc = threadIdx.x; lc < K2_CELLS; lc += 256) {   // lc = local cell: row-in-block * 112 + col
+		const int rsel = lc / DIM, col = lc % DIM;
+		const int i = cell_index(brow0 + rsel, col);
+		if (i < 0) continue;
+		// centre 8x8 = window rows 1..8, bits 1..8 of each 10-bit row
+		const uint32_t* r = s_rows + (rsel * PITCH + 1) * 32;
+		const int x0 = OFFSET + col * PITCH;                   // centre block starts one pixel right of the window origin
+		const int j = x0 >> 5, sh = 56 - (x0 & 31);
+		const int j1 = j + 1 > 31 ? 31 : j + 1;
+		uint32_t hi = 0, lo = 0;
 #pragma unroll
-			for (int k = 0; k < 10; ++k) rows[k] = 0;
+		for (int k = 0; k < 4; ++k) {
+			uint64_t v = ((uint64_t)r[k * 32 + j] << 32) | r[k * 32 + j1];
+			hi = (hi << 8) | ((uint32_t)(v >> sh) & 0xFFu);
+			uint64_t w = ((uint64_t)r[(k + 4) * 32 + j] << 32) | r[(k + 4) * 32 + j1];
+			lo = (lo << 8) | ((uint32_t)(w >> sh) & 0xFFu);
 		}
-		// lanes whose centre hash is not an exact tile: full 16-tile popcount match (wave-uniform branch: skipped entirely
-		// for the waves of a clean frame where every cell matched exactly)
-		if (__any(live && sym == 16)) {
-			if (live && sym == 16) {
-				const uint32_t centre = best_tile(hc);
-				dc = centre >> 4;
-				sym = centre & 15u;
-			}
-		}
-		if (live) {
+		const uint32_t sym = exact_tile(((uint64_t)hi << 32) | lo);
+		if (sym < 16) {
 			symbols[(size_t)f * NCELLS + i] = (uint8_t)sym;
-			if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
-		}
-
-		unsigned long long todo = __ballot(live && dc != 0);
-		while (todo) {
-			const int L = __builtin_ctzll(todo);
-			todo &= todo - 1;
-			uint32_t ur[10];
-#pragma unroll
-			for (int k = 0; k < 10; ++k) ur[k] = (uint32_t)__builtin_amdgcn_readlane((int)rows[k], L);
-			const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)dc, L);
-			const int cell = __builtin_amdgcn_readlane(i, L);
-			// side windows 5,7,3,1 on lane groups 0..3 (uniform hashes, per-lane select)
-			const uint64_t h5 = window_hash(ur, 5), h7 = window_hash(ur, 7), h3 = window_hash(ur, 3), h1 = window_hash(ur, 1);
-			uint64_t h = grp == 0 ? h5 : (grp == 1 ? h7 : (grp == 2 ? h3 : h1));
-			uint32_t best = (uint32_t)__popcll(h ^ my_tile);
-			if (is_seed(cell)) {
-				const uint64_t h8 = window_hash(ur, 8), h0 = window_hash(ur, 0), h2 = window_hash(ur, 2), h6 = window_hash(ur, 6);
-				h = grp == 0 ? h8 : (grp == 1 ? h0 : (grp == 2 ? h2 : h6));
-				const uint32_t d2 = (uint32_t)__popcll(h ^ my_tile);
-				best = d2 < best ? d2 : best;
-			}
-			if (wave_min(best) < dL) shifted = true;
+			if (dist) dist[(size_t)f * NCELLS + i] = 0;
+		} else {
+			s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)lc;
 		}
 	}
-	if (shifted && lane == 0) atomicOr(&flood_flag[f], 1u);
+	__syncthreads();
+
+	bool shifted = false;
+	const int qn = s_qn;
+	for (int q = threadIdx.x; q < qn; q += 256) {
+		const int lc = s_queue[q];
+		const int rsel = lc / DIM, col = lc % DIM;
+		const int i = cell_index(brow0 + rsel, col);
+		uint32_t rows[10];
+		window_rows_lds(s_rows + rsel * PITCH * 32, OFFSET + col * PITCH - 1, rows);
+		const uint32_t centre = best_tile(window_hash(rows, 4));
+		const uint32_t dc = centre >> 4;
+		symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
+		if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
+		if (dc != 0) {
+			uint32_t other = 0xFFFFu;
+			const int side[4] = {5, 7, 3, 1};
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { uint32_t bt = best_tile(window_hash(rows, side[k])); other = bt < other ? bt : other; }
+			if (is_seed(i)) {
+				const int corner[4] = {8, 0, 2, 6};
+#pragma unroll
+				for (int k = 0; k < 4; ++k) { uint32_t bt = best_tile(window_hash(rows, corner[k])); other = bt < other ? bt : other; }
+			}
+			shifted |= (other >> 4) < dc;
+		}
+	}
+	if (shifted) atomicOr(&flood_flag[f], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------ K2b exact flood
@@ -723,7 +716,7 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t v)
 }
 
 struct RsShared {
-	uint8_t exp[512];
+	uint8_t exp[768];         // exp[512..767] = 0: where a zero byte's "logarithm" points, so that it contributes nothing
 	uint8_t log[256];
 	uint8_t enc[4][160];      // block in transmit order
 	__attribute__((aligned(4))) uint8_t synd[4][32];
@@ -753,7 +746,7 @@ __global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, T
 	constexpr int NBLK = (BITS == 4) ? SYM_BLOCKS : COL_BLOCKS;
 	constexpr int PER_BYTE = 8 / BITS;
 	__shared__ RsShared s;
-	for (int k = threadIdx.x; k < 512; k += 256) s.exp[k] = c_gf_exp[k];
+	for (int k = threadIdx.x; k < 768; k += 256) s.exp[k] = k < 512 ? c_gf_exp[k] : (uint8_t)0;
 	s.log[threadIdx.x] = c_gf_log[threadIdx.x];
 	__syncthreads();
 
@@ -784,30 +777,37 @@ __global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, T
 	// syndromes S_j = r(alpha^(j+1)), r(x) = sum_i enc[154-i] x^i (decode.c:12-28), evaluated term-parallel: lane's byte k
 	// contributes enc[k] * alpha^((j+1)*(154-k)); the 64 partial sums are XOR-reduced across the wave, four syndromes
 	// (one per byte of a dword) at a time. No dependent chain of table look-ups, every lane busy.
-	uint32_t lg[3], stp[3], rr[3];
+	// Two roots at a time: P = (e_j, e_j+1) as packed u16, e_j = ((j+1) * (154-k)) mod 255; the next pair is P + 2*(154-k) mod 255,
+	// reduced with one packed subtract + packed min (x >= 255 ? x - 255 : x  ==  min(x, x - 255) in unsigned 16-bit).
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	uint32_t lgz[3];
+	us2 P[3], step2[3];
 #pragma unroll
 	for (int r = 0; r < 3; ++r) {
 		const int k = lane + 64 * r;
-		lg[r] = s.log[mine[r] & 0xFFu];
-		stp[r] = k < RS_BLOCK ? (uint32_t)(RS_BLOCK - 1 - k) : 0u;
-		rr[r] = 0;
+		const uint32_t sk = k < RS_BLOCK ? (uint32_t)(RS_BLOCK - 1 - k) : 0u;       // power of x this byte multiplies, < 255
+		const uint32_t s2 = 2u * sk >= 255u ? 2u * sk - 255u : 2u * sk;
+		lgz[r] = mine[r] ? (uint32_t)s.log[mine[r] & 0xFFu] : 512u;
+		P[r] = us2{(unsigned short)sk, (unsigned short)s2};
+		step2[r] = us2{(unsigned short)s2, (unsigned short)s2};
 	}
+	const us2 k255 = us2{255, 255};
 	uint32_t any_nonzero = 0;
 #pragma unroll
 	for (int jg = 0; jg < (RS_PARITY + 3) / 4; ++jg) {
 		uint32_t packed = 0;
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			if (4 * jg + q < RS_PARITY) {
-				uint32_t part = 0;
+		for (int h = 0; h < 2; ++h) {
+			if (4 * jg + 2 * h < RS_PARITY) {   // RS_PARITY is even: roots come in whole pairs
+				uint32_t part0 = 0, part1 = 0;
 #pragma unroll
 				for (int r = 0; r < 3; ++r) {
-					rr[r] += stp[r];
-					rr[r] -= rr[r] >= 255u ? 255u : 0u;
-					const uint32_t term = s.exp[lg[r] + rr[r]];
-					part ^= mine[r] ? term : 0u;
+					part0 ^= s.exp[lgz[r] + P[r].x];
+					part1 ^= s.exp[lgz[r] + P[r].y];
+					P[r] += step2[r];
+					P[r] = __builtin_elementwise_min(P[r], P[r] - k255);
 				}
-				packed |= part << (8 * q);
+				packed |= (part0 | (part1 << 8)) << (16 * h);
 			}
 		}
 		const uint32_t red = wave_xor(packed);
