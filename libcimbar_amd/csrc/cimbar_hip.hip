@@ -74,10 +74,15 @@ struct Tables {
 // Output 1: plane[frame][row][32 words], pixel x -> word x/32, bit 31-(x%32).
 // Output 2: cellmean[frame][112*112] = r | g<<8 | b<<16, the inner-6x6 mean (Cell.h:30-62: uint16 sums / 36) of every
 //           cell at its UNDRIFTED grid position -- what read_color / init_ccm sample when no drift is in play
-//           (CimbReader.cpp:133-137,216-217). Strips are aligned to the cell grid (16 strips x 7 cell rows), so a cell's
+//           (CimbReader.cpp:133-137,216-217). Strips are aligned to the cell grid (56 strips x 2 cell rows), so a cell's
 //           six inner rows always belong to one wave: per-byte column sums accumulate in registers over those rows and
 //           are regrouped into cells through a 6 KiB LDS transpose once per cell row.
-constexpr int K1_STRIPS = 16, K1_CELLROWS = DIM / K1_STRIPS;   // 7 cell rows = 63 pixel rows per strip (+8 px margin at both ends)
+// Strip height is a trade: tall strips re-read few halo rows (2*RAD per strip) but 1024 frames x 16 strips = 5.33 "rounds" of
+// the 3072 resident waves leave the chip partly idle while the last round drains; short strips drain evenly but re-read more.
+// Measured on MI355X, 1024-frame batches: 16 strips 0.73 ms, 28: 0.73, 56: 0.68, 112: 0.80. A persistent-wave work queue mixing
+// tall and short units was tried and lost to the plain grid (0.79 ms).
+constexpr int K1_STRIPS = 56, K1_CELLROWS = DIM / K1_STRIPS;   // 2 cell rows = 18 pixel rows per strip (+8 px margin at both ends of the frame)
+static_assert(DIM % K1_STRIPS == 0 && K1_STRIPS % 4 == 0, "strips must tile the cell grid and the 4-wave workgroups");
 constexpr int GRID_CELLS = DIM * DIM;
 
 __device__ __forceinline__ void load_row48(const uint8_t* __restrict__ row, int lane, uint32_t d[12])
@@ -250,6 +255,12 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 	for (int k = 0; k < 12; ++k) { acc_e[k] = 0; acc_o[k] = 0; }
 
 	auto clampy = [](int y) { return y < 0 ? 0 : (y >= IMG ? IMG - 1 : y); };   // BORDER_REPLICATE of the thresholded source
+	// Even strips walk down, odd strips walk up. A strip needs RAD rows of each neighbour; with alternating directions both
+	// owners of a boundary touch it at the same moment (both at their start, or both at their end), so the halo rows are served
+	// by L2 instead of being fetched from HBM a second time (measured: 21 % extra read traffic without this).
+	const int dir = (strip & 1) ? -1 : 1;
+	const int y_first = dir > 0 ? y_begin - RAD : y_end - 1 + RAD;     // first row visited
+	const int y_stop = dir > 0 ? y_end - 1 + RAD : y_begin - RAD;      // last row visited
 #ifndef K1_DEPTH
 #define K1_DEPTH 3
 #endif
@@ -258,23 +269,23 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 	uint32_t buf[DEPTH][12];          // row t lives in buf[t % DEPTH] and is refilled with row t+DEPTH as soon as it is consumed
 	if (!PRE) {
 #pragma unroll
-		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, clampy(y_begin - RAD + k)), lane, buf[k]);
+		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, clampy(y_first + dir * k)), lane, buf[k]);
 	}
 
 	// Straight-line body: every unrolled step runs unconditionally (rows past the strip are clamped re-reads whose results
 	// are never stored), so the refill of a consumed buffer is an unconditional load into the same registers -- no phi,
 	// no copy, and the compiler's vmcnt waits only ever cover the oldest row in flight.
-	const int y_last = clampy(y_end - 1 + RAD);
+	auto bounded = [&](int y) { return clampy(dir > 0 ? (y < y_stop ? y : y_stop) : (y > y_stop ? y : y_stop)); };
 	for (int t0 = 0; t0 < total; t0 += RING) {
 #pragma unroll
 		for (int s = 0; s < RING; ++s) {
 			const int t = t0 + s;
-			const int y = y_begin - RAD + t;
+			const int y = y_first + dir * t;
 			uint32_t (&d)[12] = buf[s % DEPTH];
 			uint32_t G[8];
 			if (PRE) {
 				uint32_t g[16];
-				sharp_row(frame, clampy(y < y_last ? y : y_last), lane, d, g);
+				sharp_row(frame, bounded(y), lane, d, g);
 				pairs_from_g(g, G);
 			} else {
 				uint32_t T[16];
@@ -292,12 +303,9 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 					acc_o[k] += __builtin_amdgcn_perm(0u, d[k], 0x0c030c01u);   // (d >> 8) & 0x00FF00FF in one op
 				}
 			}
-			if (!PRE) {   // d is dead: refill it with row t+DEPTH
-				const int yn = y + DEPTH;
-				load_row48(row_ptr(frame, clampy(yn < y_last ? yn : y_last)), lane, d);
-			}
+			if (!PRE) load_row48(row_ptr(frame, bounded(y + dir * DEPTH)), lane, d);   // d is dead: refill it with the row DEPTH steps ahead
 
-			if (ph == 6) {
+			if (ph == (dir > 0 ? 6 : 1)) {   // the cell row's last inner row in walking order
 				uint16_t* sc = s_col[wave];
 				uint2* dst = reinterpret_cast<uint2*>(sc + 48 * lane);
 #pragma unroll
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 				const uint32_t w3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x104, 0xf, 0xf, true);
 				if (t >= 2 * RAD && t < total && !(lane & 7)) {
 					uint4 v; v.x = w0; v.y = w1; v.z = w2; v.w = w3;
-					*reinterpret_cast<uint4*>(out + (size_t)(y - RAD) * 32 + (lane >> 3) * 4) = v;
+					*reinterpret_cast<uint4*>(out + (size_t)(y - dir * RAD) * 32 + (lane >> 3) * 4) = v;   // the row whose window just completed
 				}
 			}
 		}
