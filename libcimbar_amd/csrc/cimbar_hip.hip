@@ -222,8 +222,7 @@ template <int RAD, bool PRE>
 #define K1_WAVES 3
 #endif
 __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
-                                                                uint32_t* __restrict__ cellmean, uint32_t* __restrict__ flood_flag,
-                                                                unsigned long long* __restrict__ total_good, int f0)
+                                                                uint32_t* __restrict__ cellmean, uint32_t* __restrict__ flood_flag, int f0)
 {
 	constexpr int RING = 2 * RAD + 2;
 	__shared__ __attribute__((aligned(16))) uint16_t s_col[4][IMG * 3];   // per-wave column sums of one cell row, by row byte
@@ -237,10 +236,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 	const int y_begin = strip == 0 ? 0 : OFFSET + strip * K1_CELLROWS * PITCH;
 	const int y_end = strip == K1_STRIPS - 1 ? IMG : OFFSET + (strip + 1) * K1_CELLROWS * PITCH;
 	const int total = (y_end - y_begin) + 2 * RAD;
-	if (strip == 0 && lane == 0) {   // per-batch state the later kernels accumulate into
-		flood_flag[f] = 0;
-		if (blockIdx.y == 0) *total_good = 0;
-	}
+	if (strip == 0 && lane == 0) flood_flag[f] = 0;   // per-frame state k_symbols accumulates into
 
 	uint32_t ring[RING][8];
 	uint32_t C[8];
@@ -934,11 +930,11 @@ __device__ __forceinline__ void md_increment(uint8_t h[6], unsigned radioactive)
 	h[5] = (uint8_t)(next & 0xFF);
 }
 
-struct FrameState {           // aligned_stream + CimbReader metadata state carried from the symbol to the colour pass
+struct FrameState {           // aligned_stream state carried from the symbol to the colour pass
 	uint32_t offset;          // aligned_stream::_offset
 	uint32_t bad;             // aligned_stream::_badChunk
-	uint32_t mask;            // chunks delivered so far
-	uint32_t total;           // aligned_stream::_totalCount
+	uint32_t mask;            // chunks delivered so far (aligned_stream::_totalCount == 625 * popcount(mask))
+	uint32_t pad;
 };
 
 // aligned_stream.h:39-119 driven one 125-byte RS block at a time (reed_solomon_stream.h:62-74,109-114). A bad LAST block of
@@ -952,7 +948,7 @@ __device__ __forceinline__ void aligner_block(FrameState& st, int block_no, int 
 	if (RS_DATA + st.offset >= (unsigned)CHUNK) {
 		const bool delivered = !st.bad;
 		if (st.bad) { st.bad = 0; st.offset = 0; }
-		else { st.mask |= 1u << chunk_index; st.total += CHUNK; st.offset = 0; }
+		else { st.mask |= 1u << chunk_index; st.offset = 0; }
 		if (track_md) {
 			if (!delivered && md_id(hdr) == 0) return;                       // update_metadata(nullptr, 0)
 			if (md_id(hdr) == 0) { for (int k = 0; k < 6; ++k) hdr[k] = frame_chunks[(size_t)chunk_index * CHUNK + k]; }
@@ -1314,7 +1310,7 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 // K7: chunk bookkeeping for the colour blocks, final mask, zero the slots of dropped chunks, per-frame good bytes
 __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
                                                   uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
-                                                  unsigned long long* __restrict__ total_good, const float* __restrict__ ccm_used,
+                                                  const float* __restrict__ ccm_used,
                                                   float* __restrict__ carry, int f0)
 {
 	const int f = f0 + blockIdx.x, lane = threadIdx.x;
@@ -1330,7 +1326,6 @@ __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs
 		states[f] = st;
 		masks[f] = st.mask;
 		s_mask = st.mask;
-		atomicAdd(total_good, (unsigned long long)st.total);
 	}
 	__syncthreads();
 	const uint32_t mask = s_mask;
@@ -1376,7 +1371,6 @@ struct cimbar_hip_ctx {
 	float* d_carry = nullptr;         // 10 floats
 	uint8_t* d_chunks = nullptr;      // staging for host-resident output
 	uint32_t* d_masks = nullptr;
-	unsigned long long* d_total = nullptr;
 	FloodScratch flood{};
 	int flood_cap = 0;
 	// timing
@@ -1530,7 +1524,7 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.adj);
 	fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
 	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
-	fr(ctx->d_masks); fr(ctx->d_total); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
+	fr(ctx->d_masks); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1548,8 +1542,8 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(mark());
 	{
 		dim3 g(K1_STRIPS / 4, n);
-		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, ctx->d_total, f0);
-		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, ctx->d_total, f0);
+		if (pre) hipLaunchKernelGGL((k_threshold<3, true>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, f0);
+		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, f0);
 	}
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
@@ -1564,7 +1558,7 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(mark());
 	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, f0, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_total, ctx->d_ccm_used, ctx->d_carry, f0);
+	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_ccm_used, ctx->d_carry, f0);
 	HIPCHK(mark());
 	HIPCHK(hipGetLastError());
 	ctx->last_n = n;
@@ -1596,7 +1590,6 @@ int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out)
 	for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	if (hipMalloc(&ctx->d_carry, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_ENOMEM);
 	if (hipMemset(ctx->d_carry, 0, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
-	if (hipMalloc(&ctx->d_total, sizeof(unsigned long long)) != hipSuccess) return fail(CIMBAR_HIP_ENOMEM);
 	if (build_tables(ctx) != 0) return fail(CIMBAR_HIP_EHIP);
 	*out = ctx;
 	return CIMBAR_HIP_OK;
@@ -1654,10 +1647,11 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 	unsigned long long total = 0;
 	HIPCHK(hipMemcpyAsync(chunks, d_chunks, (size_t)n * FRAME_BYTES, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(masks, d_masks, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-	HIPCHK(hipMemcpyAsync(&total, ctx->d_total, sizeof total, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	if (ctx->timing)
 		for (int k = 0; k < cimbar_hip_ctx::NSTAGE; ++k) HIPCHK(hipEventElapsedTime(&ctx->stage_ms[k], ctx->ev[k], ctx->ev[k + 1]));
+	// aligned_stream::tellp() summed over the batch: 625 bytes per delivered chunk (aligned_stream.h:29-32)
+	for (int f = 0; f < n; ++f) total += (unsigned long long)CHUNK * (unsigned)__builtin_popcount(masks[f] & 0xFFFu);
 	return (int64_t)total;
 }
 
