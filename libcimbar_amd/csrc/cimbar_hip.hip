@@ -827,38 +827,64 @@ __global__ __launch_bounds__(256) void k_rs(const uint8_t* __restrict__ cells, T
 		uint8_t* loc = s.loc[wv];
 		uint8_t* last = s.last[wv];
 		const uint8_t* synd = s.synd[wv];
-		__shared__ int s_order[4];
-		if (lane == 0) {
-			// Berlekamp-Massey, decode.c:32-118, literal
-			for (int k = 0; k < 72; ++k) { loc[k] = 0; last[k] = 0; }
-			loc[0] = 1; last[0] = 1;
-			unsigned loc_order = 0, last_order = 0, numerrors = 0, delay = 1;
-			uint8_t last_disc = 1;
-			for (unsigned i = 0; i < (unsigned)RS_PARITY; ++i) {
-				uint8_t disc = synd[i];
-				for (unsigned j = 1; j <= numerrors; ++j) disc ^= gf_mul(s, loc[j], synd[i - j]);
-				if (!disc) { delay++; continue; }
-				if (2 * numerrors <= i) {
-					for (int j = (int)last_order; j >= 0; --j) last[j + delay] = gf_div(s, gf_mul(s, last[j], disc), last_disc);
-					for (int j = (int)delay - 1; j >= 0; --j) last[j] = 0;
-					for (unsigned j = 0; j <= last_order + delay; ++j) { uint8_t t = loc[j]; loc[j] ^= last[j]; last[j] = t; }
-					unsigned t_order = loc_order;
-					loc_order = last_order + delay;
-					last_order = t_order;
-					numerrors = i + 1 - numerrors;
-					last_disc = disc;
-					delay = 1;
-					continue;
-				}
-				for (int j = (int)last_order; j >= 0; --j) loc[j + delay] ^= gf_div(s, gf_mul(s, last[j], disc), last_disc);
-				loc_order = (last_order + delay > loc_order) ? last_order + delay : loc_order;
-				delay++;
-			}
-			s_order[wv] = (int)loc_order;
-		}
+		// Berlekamp-Massey, decode.c:32-118. The control flow (discrepancy test, "room for more taps" test, orders, delay) is
+		// libcorrect's, statement for statement; its array loops are element-wise, so lane k carries element k (and k+64) of
+		// the locator / previous locator and all elements move at once. Entries above the loops' bounds keep their stale
+		// values exactly as they do in libcorrect's buffers.
+		for (int k = lane; k < 72; k += 64) { loc[k] = (k == 0); last[k] = (k == 0); }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+		unsigned loc_order = 0, last_order = 0, numerrors = 0, delay = 1;
+		uint8_t last_disc = 1;
+		for (unsigned i = 0; i < (unsigned)RS_PARITY; ++i) {
+			uint32_t part = 0;
+			if (lane >= 1 && (unsigned)lane <= numerrors) part = gf_mul(s, loc[lane], synd[i - lane]);
+			const uint8_t disc = (uint8_t)((synd[i] ^ wave_xor(part)) & 0xFFu);
+			if (!disc) { delay++; continue; }
+			if (2 * numerrors <= i) {
+				// last <- (last * disc / last_disc) shifted up by `delay`; then loc <- loc - last, last <- old loc, over [0, last_order + delay]
+				uint8_t nloc[2] = {0, 0}, nlast[2] = {0, 0};
+#pragma unroll
+				for (int hh = 0; hh < 2; ++hh) {
+					const unsigned k = (unsigned)lane + 64u * hh;
+					if (k < 72u) {
+						const uint8_t oloc = loc[k], olast = last[k];
+						const uint8_t shifted = k < delay ? (uint8_t)0
+						                        : (k - delay <= last_order ? gf_div(s, gf_mul(s, last[k - delay], disc), last_disc) : olast);
+						if (k <= last_order + delay) { nloc[hh] = oloc ^ shifted; nlast[hh] = oloc; }
+						else { nloc[hh] = oloc; nlast[hh] = shifted; }
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+				for (int hh = 0; hh < 2; ++hh) {
+					const unsigned k = (unsigned)lane + 64u * hh;
+					if (k < 72u) { loc[k] = nloc[hh]; last[k] = nlast[hh]; }
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				const unsigned t_order = loc_order;
+				loc_order = last_order + delay;
+				last_order = t_order;
+				numerrors = i + 1 - numerrors;
+				last_disc = disc;
+				delay = 1;
+				continue;
+			}
+			// no more taps: loc[j + delay] -= last[j] * disc / last_disc for j <= last_order (last is not touched)
+#pragma unroll
+			for (int hh = 0; hh < 2; ++hh) {
+				const unsigned k = (unsigned)lane + 64u * hh;
+				if (k < 72u && k >= delay && k - delay <= last_order) loc[k] ^= gf_div(s, gf_mul(s, last[k - delay], disc), last_disc);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			loc_order = (last_order + delay > loc_order) ? last_order + delay : loc_order;
+			delay++;
+		}
+		const int order = (int)loc_order;
 		__builtin_amdgcn_s_waitcnt(0);
-		const int order = s_order[wv];
 
 		// error evaluator = locator * S mod x^30 (decode.c:149-161, polynomial.c:17-30): coefficient k on lane k
 		if (lane < RS_PARITY) {
