@@ -33,13 +33,16 @@ ALGO_BYTES_PER_FRAME = modeb.FRAME_RGB_BYTES + modeb.FRAME_BYTES + 4   # 3 153 2
 HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_frames(n, device, seed):
-    synth = framegen.FrameSynth(device)
+def make_frames(n, device, seed, dec):
+    """Synthetic clean mode-B frames, rendered on the device by the library's encode half (cimbar_hip_encode_batch, checked
+    byte-for-byte against the reference encoder in tests/test_gpu_encode.py); 16 of them are cross-checked here against the
+    torch restatement of Encoder::encode_next."""
     payload = framegen.synth_payload(n, seed=seed, device=device)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=device)
-    step = 64
-    for lo in range(0, n, step):
-        synth.frames_from_payload(payload[lo:lo + step], out=frames[lo:lo + step])
+    dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+    k = min(n, 16)
+    if not bool((frames[:k] == framegen.FrameSynth(device).frames_from_payload(payload[:k])).all().item()):
+        raise SystemExit("bench: device-rendered frames differ from the reference layout")
     return payload, frames
 
 
@@ -134,10 +137,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.frames
-    payload, frames = make_frames(n, dev, seed=1234 + rank)
+    dec = HipDecoder(local_rank)
+    payload, frames = make_frames(n, dev, seed=1234 + rank, dec=dec)
     chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
     masks = torch.zeros((n,), dtype=torch.int32, device=dev)
-    dec = HipDecoder(local_rank)
     stream = torch.cuda.current_stream(dev)
 
     def step():

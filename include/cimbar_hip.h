@@ -80,6 +80,17 @@ int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx);
 /* Current carried CCM, row-major 3x3; returns 1 if active, 0 if not (CimbDecoder::get_ccm, CimbDecoder.cpp:76-80). */
 int cimbar_hip_get_ccm(cimbar_hip_ctx* ctx, float out9[9]);
 
+/* ---- the encode half ("next" row of the scope table: on-device frame synthesiser) --------------------------------------------
+ * Encoder::encode_next (src/lib/encoder/Encoder.h:69-129) for n frames at once: each frame takes 7500 payload bytes (the 60
+ * reads of 125 bytes a fountain_encoder_stream / ifstream would have served), RS(155,125)-encodes them (libcorrect encode.c:3-34),
+ * stripes the 4 symbol bits and 2 colour bits of every cell through the interleave (CimbWriter.cpp:84-95, Interleave.h:8-24) and
+ * pastes tile colour*16+symbol (Common.cpp:150-171) at every cell of a 1024x1024 RGB8 frame.
+ * The background / anchors / guides come from a template frame the caller supplies once (an empty CimbWriter image,
+ * CimbWriter.cpp:39-77): this library ships no bitmap assets of its own. */
+int cimbar_hip_set_template(cimbar_hip_ctx* ctx, const uint8_t* rgb_template, int mem);
+int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, int payload_mem, uint8_t* rgb_out, int rgb_mem,
+                            void* hip_stream);
+
 /* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
 enum {
 	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */

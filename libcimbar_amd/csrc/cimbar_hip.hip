@@ -1361,6 +1361,97 @@ __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs
 			for (int k = lane; k < CHUNK; k += 64) fc[(size_t)j * CHUNK + k] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------ encode half (frame synthesiser)
+// E1: RS(155,125) encode, one block per wavefront (libcorrect encode.c:3-34: systematic, remainder of msg(x)*x^30 by the
+// generator prod_{i=1..30}(x + alpha^i)). Lane j < 30 holds remainder coefficient j; every message byte is one LFSR step:
+// fb = msg[i] ^ rem[29], rem[j] = rem[j-1] ^ fb * g[j]. The 155 code bytes are then split into per-cell symbol / colour values
+// and scattered through the interleave map (Encoder.h:95-119: 4-bit symbols for blocks 0..39, 2-bit colours for 40..59).
+__global__ __launch_bounds__(256) void k_rs_encode(const uint8_t* __restrict__ payload, Tables tb, const uint8_t* __restrict__ gen_log,
+                                                   int nframes, uint8_t* __restrict__ symbols, uint8_t* __restrict__ colors)
+{
+	__shared__ uint8_t s_exp[512], s_log[256];
+	__shared__ uint8_t s_code[4][160];
+	for (int k = threadIdx.x; k < 512; k += 256) s_exp[k] = c_gf_exp[k];
+	s_log[threadIdx.x] = c_gf_log[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int gb = blockIdx.x * 4 + wv;
+	if (gb / ALL_BLOCKS >= nframes) return;
+	const int f = gb / ALL_BLOCKS, b = gb % ALL_BLOCKS;
+	const uint8_t* msg = payload + (size_t)f * FRAME_BYTES + (size_t)b * RS_DATA;
+	uint8_t* code = s_code[wv];
+	for (int k = lane; k < RS_DATA; k += 64) code[k] = msg[k];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t glog = lane < RS_PARITY ? gen_log[lane] : 0u;      // log of generator coefficient j (all non-zero)
+	uint32_t rem = 0;
+	for (int i = 0; i < RS_DATA; ++i) {
+		const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)rem, RS_PARITY - 1);
+		const uint32_t fb = (uint32_t)code[i] ^ top;                      // uniform
+		const uint32_t prev = from_left_lane(rem, 0u);                     // rem[j-1], 0 into lane 0
+		const uint32_t prod = fb ? (uint32_t)s_exp[(uint32_t)s_log[fb] + glog] : 0u;
+		rem = lane < RS_PARITY ? (prev ^ prod) : 0u;
+	}
+	if (lane < RS_PARITY) code[RS_DATA + (RS_PARITY - 1 - lane)] = (uint8_t)rem;   // parity, highest order first
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	for (int k = lane; k < RS_BLOCK; k += 64) {
+		const uint32_t v = code[k];
+		if (b < SYM_BLOCKS) {
+			const int sidx = (RS_BLOCK * b + k) * 2;
+			symbols[(size_t)f * NCELLS + tb.stream_cell[sidx]] = (uint8_t)(v >> 4);
+			symbols[(size_t)f * NCELLS + tb.stream_cell[sidx + 1]] = (uint8_t)(v & 15u);
+		} else {
+			const int sidx = (RS_BLOCK * (b - SYM_BLOCKS) + k) * 4;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) colors[(size_t)f * NCELLS + tb.stream_cell[sidx + q]] = (uint8_t)((v >> (6 - 2 * q)) & 3u);
+		}
+	}
+}
+
+// E2: render. Output-driven and write-coalesced: one wavefront per pixel row, lane l writes pixels [16l, 16l+16) as three
+// 16-byte stores. A pixel inside a cell takes the palette colour where the tile has a foreground bit, black elsewhere
+// (Common.cpp:150-171, dark mode); every other pixel comes from the template (CimbWriter.cpp:39-77).
+__global__ __launch_bounds__(256) void k_render(const uint8_t* __restrict__ symbols, const uint8_t* __restrict__ colors,
+                                                const uint8_t* __restrict__ tmpl, uint8_t* __restrict__ rgb)
+{
+	const int lane = threadIdx.x & 63;
+	const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int f = blockIdx.y;
+	const uint4* trow = reinterpret_cast<const uint4*>(tmpl + (size_t)y * IMG * 3 + lane * 48);
+	uint4 t0 = trow[0], t1 = trow[1], t2 = trow[2];
+	uint32_t d[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+	const int ry = y - OFFSET;
+	if (ry >= 0 && ry < DIM * PITCH && ry % PITCH < 8) {
+		const int row = ry / PITCH, dy = ry % PITCH;
+#pragma unroll
+		for (int p = 0; p < 16; ++p) {
+			const int rx = lane * 16 + p - OFFSET;
+			const int col = rx / PITCH, dx = rx - col * PITCH;
+			if (rx >= 0 && col < DIM && dx < 8) {
+				const int i = cell_index(row, col);
+				if (i >= 0) {
+					const uint32_t sym = symbols[(size_t)f * NCELLS + i], colr = colors[(size_t)f * NCELLS + i];
+					const bool fg = (c_tile[sym] >> (63 - (dy * 8 + dx))) & 1ull;
+					const uint32_t r = fg ? (uint32_t)c_palette[colr][0] : 0u, g = fg ? (uint32_t)c_palette[colr][1] : 0u,
+					               bl = fg ? (uint32_t)c_palette[colr][2] : 0u;
+					// bytes 3p, 3p+1, 3p+2 of the lane's 48
+#pragma unroll
+					for (int ch = 0; ch < 3; ++ch) {
+						const int k = 3 * p + ch;
+						const uint32_t v = ch == 0 ? r : (ch == 1 ? g : bl);
+						d[k >> 2] = (d[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | (v << (8 * (k & 3)));
+					}
+				}
+			}
+		}
+	}
+	uint4* orow = reinterpret_cast<uint4*>(rgb + (size_t)f * FRAME_RGB + (size_t)y * IMG * 3 + lane * 48);
+	orow[0] = make_uint4(d[0], d[1], d[2], d[3]);
+	orow[1] = make_uint4(d[4], d[5], d[6], d[7]);
+	orow[2] = make_uint4(d[8], d[9], d[10], d[11]);
+}
+
 // repack the internal word-oriented bitplane into CimbReader::_grayscale's byte layout (tap only)
 __global__ void k_plane_bytes(const uint32_t* __restrict__ plane, uint8_t* __restrict__ out, size_t nwords)
 {
@@ -1395,6 +1486,10 @@ struct cimbar_hip_ctx {
 	float* d_ccm_frames = nullptr;
 	float* d_ccm_used = nullptr;
 	float* d_carry = nullptr;         // 10 floats
+	uint8_t* d_template = nullptr;    // encode half: empty frame (background, anchors, guides)
+	uint8_t* d_gen_log = nullptr;     // encode half: logs of the 30 low generator coefficients
+	uint8_t* d_payload = nullptr;     // encode half: staging for host-resident payload
+	size_t d_payload_cap = 0;
 	uint8_t* d_chunks = nullptr;      // staging for host-resident output
 	uint32_t* d_masks = nullptr;
 	FloodScratch flood{};
@@ -1508,6 +1603,18 @@ int build_tables(cimbar_hip_ctx* ctx)
 	HIPCHK(hipMemcpy(ctx->tb.adj, adj.data(), sizeof(int16_t) * NCELLS * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_exp), gexp, 512));
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_log), glog, 256));
+	// generator polynomial prod_{i=1..30} (x + alpha^i), low -> high (libcorrect reed-solomon.c:5-12, polynomial.c:205-240)
+	uint8_t gen[RS_PARITY + 1] = {1};
+	auto gmul = [&](uint8_t a, uint8_t b) -> uint8_t { return (!a || !b) ? 0 : gexp[(unsigned)glog[a] + glog[b]]; };
+	for (int i = 0; i < RS_PARITY; ++i) {
+		const uint8_t root = gexp[(i + 1) % 255];
+		for (int j = i + 1; j >= 1; --j) gen[j] = gen[j - 1] ^ gmul(gen[j], root);
+		gen[0] = gmul(gen[0], root);
+	}
+	uint8_t gen_log[RS_PARITY];
+	for (int j = 0; j < RS_PARITY; ++j) gen_log[j] = glog[gen[j]];
+	HIPCHK(hipMalloc(&ctx->d_gen_log, RS_PARITY));
+	HIPCHK(hipMemcpy(ctx->d_gen_log, gen_log, RS_PARITY, hipMemcpyHostToDevice));
 	return 0;
 }
 
@@ -1548,7 +1655,7 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	(void)hipSetDevice(ctx->device);
 	auto fr = [](void* p) { if (p) (void)hipFree(p); };
 	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.adj);
-	fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
+	fr(ctx->d_template); fr(ctx->d_gen_log); fr(ctx->d_payload); fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
 	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
 	fr(ctx->d_masks); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1693,6 +1800,48 @@ int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
 	std::vector<uint8_t> packed(FRAME_RGB);
 	for (int y = 0; y < IMG; ++y) std::memcpy(packed.data() + (size_t)y * IMG * 3, rgb + (size_t)y * stride, (size_t)IMG * 3);
 	return (int)cimbar_hip_decode_batch(ctx, packed.data(), 1, CIMBAR_HIP_MEM_HOST, should_preprocess, color_correction, chunks, good_mask, CIMBAR_HIP_MEM_HOST, nullptr);
+}
+
+int cimbar_hip_set_template(cimbar_hip_ctx* ctx, const uint8_t* rgb_template, int mem)
+{
+	if (!ctx || !rgb_template) return CIMBAR_HIP_EINVAL;
+	HIPCHK(hipSetDevice(ctx->device));
+	if (!ctx->d_template) HIPCHK(hipMalloc(&ctx->d_template, FRAME_RGB));
+	HIPCHK(hipMemcpy(ctx->d_template, rgb_template, FRAME_RGB, mem == CIMBAR_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+	return 0;
+}
+
+int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, int payload_mem, uint8_t* rgb_out, int rgb_mem,
+                            void* hip_stream)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (!payload || !rgb_out || n <= 0) { ctx->err = "encode_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
+	if (!ctx->d_template) { ctx->err = "encode_batch: call cimbar_hip_set_template first"; return CIMBAR_HIP_EINVAL; }
+	HIPCHK(hipSetDevice(ctx->device));
+	const bool any_device = payload_mem == CIMBAR_HIP_MEM_DEVICE || rgb_mem == CIMBAR_HIP_MEM_DEVICE;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
+	if (int r = ensure_capacity(ctx, n)) return r;
+	const uint8_t* d_payload = payload;
+	if (payload_mem == CIMBAR_HIP_MEM_HOST) {
+		const size_t need = (size_t)n * FRAME_BYTES;
+		if (need > ctx->d_payload_cap) { HIPCHK(regrow(ctx->d_payload, need)); ctx->d_payload_cap = need; }
+		HIPCHK(hipMemcpyAsync(ctx->d_payload, payload, need, hipMemcpyHostToDevice, st));
+		d_payload = ctx->d_payload;
+	}
+	uint8_t* d_out = rgb_out;
+	if (rgb_mem == CIMBAR_HIP_MEM_HOST) {
+		const size_t need = (size_t)n * FRAME_RGB;
+		if (need > ctx->d_rgb_cap) { HIPCHK(regrow(ctx->d_rgb, need)); ctx->d_rgb_cap = need; }
+		d_out = ctx->d_rgb;
+	}
+	hipLaunchKernelGGL(k_rs_encode, dim3((n * ALL_BLOCKS + 3) / 4), dim3(256), 0, st, d_payload, ctx->tb, ctx->d_gen_log, n, ctx->d_symbols, ctx->d_colors);
+	hipLaunchKernelGGL(k_render, dim3(IMG / 4, n), dim3(256), 0, st, ctx->d_symbols, ctx->d_colors, ctx->d_template, d_out);
+	HIPCHK(hipGetLastError());
+	if (rgb_mem == CIMBAR_HIP_MEM_HOST) {
+		HIPCHK(hipMemcpyAsync(rgb_out, d_out, (size_t)n * FRAME_RGB, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+	}
+	return 0;
 }
 
 int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes)

@@ -23,7 +23,7 @@ TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM 
 EXPORTS = (
     "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
-    "cimbar_hip_stage_times",
+    "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch",
 )
 
 
@@ -67,6 +67,10 @@ def load_library(path=None):
     lib.cimbar_hip_enable_timing.restype = i32
     lib.cimbar_hip_stage_times.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), i32]
     lib.cimbar_hip_stage_times.restype = i32
+    lib.cimbar_hip_set_template.argtypes = [vp, vp, i32]
+    lib.cimbar_hip_set_template.restype = i32
+    lib.cimbar_hip_encode_batch.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.cimbar_hip_encode_batch.restype = i32
     if path is None:
         _lib = lib
     return lib
@@ -156,6 +160,34 @@ class HipDecoder:
                 if mask & (1 << j):
                     ostream.write(chunks[j].tobytes())
         return good
+
+    # ------------------------------------------------------------------ encode half (frame synthesiser)
+    def _ensure_template(self):
+        if getattr(self, "_have_template", False):
+            return
+        path = os.path.join(_HERE, "data", "modeb_template.npz")
+        z = np.load(path)
+        t = np.zeros(modeb.FRAME_RGB_BYTES, dtype=np.uint8)
+        t[z["idx"]] = z["val"]
+        self._check(self._lib.cimbar_hip_set_template(self._ctx, t.ctypes.data, MEM_HOST), "cimbar_hip_set_template")
+        self._have_template = True
+
+    def encode_batch(self, payload):
+        """payload (n,7500) uint8 numpy -> frames (n,1024,1024,3) uint8 numpy (Encoder::encode_next for n frames)."""
+        self._ensure_template()
+        payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(-1, modeb.FRAME_BYTES)
+        n = payload.shape[0]
+        out = np.empty((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        self._check(self._lib.cimbar_hip_encode_batch(self._ctx, payload.ctypes.data, n, MEM_HOST, out.ctypes.data, MEM_HOST, None),
+                    "cimbar_hip_encode_batch")
+        return out
+
+    def encode_batch_device(self, payload_ptr, n, rgb_ptr, stream=None):
+        """Device pointers in and out; asynchronous on `stream` (None / 0 = the null stream)."""
+        self._ensure_template()
+        self._check(self._lib.cimbar_hip_encode_batch(self._ctx, ctypes.c_void_p(payload_ptr), int(n), MEM_DEVICE, ctypes.c_void_p(rgb_ptr),
+                                                      MEM_DEVICE, ctypes.c_void_p(stream) if stream else None),
+                    "cimbar_hip_encode_batch(device)")
 
     # ------------------------------------------------------------------ state / taps / timing
     def reset_ccm(self):
