@@ -139,15 +139,32 @@ def main():
     n = args.frames
     dec = HipDecoder(local_rank)
     payload, frames = make_frames(n, dev, seed=1234 + rank, dec=dec)
-    chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
-    masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+    # two sets of output buffers: with N > 1 the gather of step k (RCCL, its own stream) overlaps the decode of step k+1
+    outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev))
+            for _ in range(2)]
+    gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev),
+                 torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(2)]
+    pending = [[], []]
     stream = torch.cuda.current_stream(dev)
+    step_no = [0]
 
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        for w in pending[k]:          # the exchange that last used this buffer set must be over before it is overwritten
+            w.wait()
+        chunks, masks = outs[k]
         dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
         if world > 1:
-            return multigpu.gather_chunks(chunks, masks, dst=0)
+            all_c, all_m, pending[k] = multigpu.gather_chunks(chunks, masks, dst=0, out=gathered[k], async_op=True)
+            return all_c, all_m
         return chunks, masks
+
+    def drain():
+        for k in (0, 1):
+            for w in pending[k]:
+                w.wait()
+            pending[k] = []
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -157,11 +174,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     stage_acc = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         all_chunks, all_masks = step()
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -170,9 +189,11 @@ def main():
         elapsed = float(t.item())
 
     # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered
+    chunks, masks = outs[(step_no[0] - 1) & 1]
     ok = bool((masks == 0xFFF).all().item()) and bool((chunks == payload).all().item())
     if world > 1 and rank == 0:
-        ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item())
+        ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item()) \
+            and bool((all_masks == 0xFFF).all().item())
     if not ok:
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
@@ -180,6 +201,7 @@ def main():
     # the library runs the batch un-sliced on one stream (one launch per kernel), so each figure is one kernel's duration.
     dec.enable_timing(True)
     reps = 5
+    chunks, masks = outs[0]
     for _ in range(reps):
         dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
         torch.cuda.synchronize(dev)

@@ -1757,6 +1757,10 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 {
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	if (!rgb || !chunks || !masks || n <= 0) { ctx->err = "decode_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
+	if ((rgb_mem != CIMBAR_HIP_MEM_HOST && rgb_mem != CIMBAR_HIP_MEM_DEVICE) || (out_mem != CIMBAR_HIP_MEM_HOST && out_mem != CIMBAR_HIP_MEM_DEVICE)) {
+		ctx->err = "decode_batch: rgb_mem / out_mem must be CIMBAR_HIP_MEM_HOST or CIMBAR_HIP_MEM_DEVICE";
+		return CIMBAR_HIP_EINVAL;
+	}
 	HIPCHK(hipSetDevice(ctx->device));
 	// NULL means what it means for any HIP launch -- the (legacy) null stream -- whenever a device buffer is involved, so the
 	// work is ordered after whatever produced the frames there; the all-host path synchronises anyway and uses its own stream
@@ -1817,6 +1821,10 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	if (!payload || !rgb_out || n <= 0) { ctx->err = "encode_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
 	if (!ctx->d_template) { ctx->err = "encode_batch: call cimbar_hip_set_template first"; return CIMBAR_HIP_EINVAL; }
+	if ((payload_mem != CIMBAR_HIP_MEM_HOST && payload_mem != CIMBAR_HIP_MEM_DEVICE) || (rgb_mem != CIMBAR_HIP_MEM_HOST && rgb_mem != CIMBAR_HIP_MEM_DEVICE)) {
+		ctx->err = "encode_batch: payload_mem / rgb_mem must be CIMBAR_HIP_MEM_HOST or CIMBAR_HIP_MEM_DEVICE";
+		return CIMBAR_HIP_EINVAL;
+	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const bool any_device = payload_mem == CIMBAR_HIP_MEM_DEVICE || rgb_mem == CIMBAR_HIP_MEM_DEVICE;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
@@ -1847,6 +1855,7 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
 int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes)
 {
 	if (!ctx || !out) return CIMBAR_HIP_EINVAL;
+	if (ctx->last_n <= 0) { ctx->err = "tap: no batch has been decoded on this context yet"; return CIMBAR_HIP_EINVAL; }
 	HIPCHK(hipSetDevice(ctx->device));
 	HIPCHK(hipDeviceSynchronize());
 	const size_t n = (size_t)ctx->last_n;

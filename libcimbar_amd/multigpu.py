@@ -19,22 +19,30 @@ def shard_range(n_frames, rank, world):
     return lo, hi, per
 
 
-def gather_chunks(chunks, masks, dst=0, group=None):
+def gather_chunks(chunks, masks, dst=0, group=None, out=None, async_op=False):
     """chunks: (n_r, 7500) uint8, masks: (n_r,) int32 on every rank (same n_r everywhere). On `dst` returns
-    (chunks (W*n_r, 7500), masks (W*n_r,)) in rank order == frame order; elsewhere (None, None)."""
+    (chunks (W*n_r, 7500), masks (W*n_r,)) in rank order == frame order; elsewhere (None, None).
+    out: optional preallocated (chunks (W*n_r,7500), masks (W*n_r,)) on `dst` (no allocation / concatenation per call).
+    async_op: return (all_chunks, all_masks, [work handles]) without waiting -- the caller overlaps the exchange with the next
+    batch's decode and calls .wait() on the handles before touching the buffers again."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
-        return chunks, masks
+        return (chunks, masks, []) if async_op else (chunks, masks)
+    works = []
     if rank == dst:
-        cl = [torch.empty_like(chunks) for _ in range(world)]
-        ml = [torch.empty_like(masks) for _ in range(world)]
-        dist.gather(chunks, cl, dst=dst, group=group)
-        dist.gather(masks, ml, dst=dst, group=group)
-        return torch.cat(cl, 0), torch.cat(ml, 0)
-    dist.gather(chunks, None, dst=dst, group=group)
-    dist.gather(masks, None, dst=dst, group=group)
-    return None, None
+        if out is None:
+            n_r = chunks.shape[0]
+            out = (torch.empty((world * n_r, chunks.shape[1]), dtype=chunks.dtype, device=chunks.device),
+                   torch.empty((world * n_r,), dtype=masks.dtype, device=masks.device))
+        all_c, all_m = out
+        works.append(dist.gather(chunks, list(all_c.chunk(world, 0)), dst=dst, group=group, async_op=async_op))
+        works.append(dist.gather(masks, list(all_m.chunk(world, 0)), dst=dst, group=group, async_op=async_op))
+    else:
+        all_c = all_m = None
+        works.append(dist.gather(chunks, None, dst=dst, group=group, async_op=async_op))
+        works.append(dist.gather(masks, None, dst=dst, group=group, async_op=async_op))
+    return (all_c, all_m, works) if async_op else (all_c, all_m)
 
 
 def feed_sink(sink_decode_frame, chunks, masks, on_complete=None):
