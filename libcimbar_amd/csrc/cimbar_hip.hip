@@ -171,6 +171,30 @@ __device__ __forceinline__ void sharp_row(const uint8_t* __restrict__ frame, int
 	}
 }
 
+// The same filter on u16 pairs (pixel i | pixel i+8 << 16) for the streaming path: gn / gc / gs are the gray rows above, at and
+// below the output row. Biased by 4096 per half so every intermediate stays a positive 16-bit field:
+//   t' = 9c - 2(n+s+w+e) + 4096 in [2056, 6391];  q' = t' >> 1 (+1 if t' odd and q' odd: half -> even; 2048 keeps the parity);
+//   result = clamp(q' - 2048, 0, 255).
+__device__ __forceinline__ void sharp_pairs(const uint32_t (&gn)[8], const uint32_t (&gc)[8], const uint32_t (&gs)[8], uint32_t (&G)[8])
+{
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	// BORDER_REFLECT_101 at the row ends: pixel -1 -> pixel 1 (lane 0), pixel 16 of lane 63 -> pixel 14
+	const uint32_t W0 = from_left_lane(gc[7] >> 16, gc[1] & 0xFFFFu) | (gc[7] << 16);            // (pixel -1, pixel 7)
+	const uint32_t E7 = (gc[0] >> 16) | (from_right_lane(gc[0] & 0xFFFFu, gc[6] >> 16) << 16);   // (pixel 8, pixel 16)
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint32_t w = i == 0 ? W0 : gc[i - 1], e = i == 7 ? E7 : gc[i + 1];
+		const uint32_t sum = gn[i] + gs[i] + w + e;
+		const uint32_t t = gc[i] * 9u + 0x10001000u - 2u * sum;
+		uint32_t q = (t >> 1) & 0x7FFF7FFFu;
+		q += t & q & 0x00010001u;
+		us2 v = __builtin_bit_cast(us2, q);
+		const us2 lo = {2048, 2048}, hi = {2048 + 255, 2048 + 255};
+		v = __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi);
+		G[i] = __builtin_bit_cast(uint32_t, v) - 0x08000800u;
+	}
+}
+
 // One row of the streaming box-threshold. All per-pixel quantities travel as u16 pairs (pixel i | pixel i+8 << 16), i < 8,
 // so a horizontal neighbour is simply the next register and plain 32-bit adds never carry between the halves.
 //   ring : the last RING gray rows (RING = 2*RAD+2, even, so that the A/B prefetch buffers keep static roles)
@@ -260,10 +284,31 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 #ifndef K1_DEPTH
 #define K1_DEPTH 3
 #endif
-	constexpr int DEPTH = K1_DEPTH;   // rows in flight per wave; RING % DEPTH == 0 keeps the buffer roles static after unrolling
-	static_assert(PRE || RING % DEPTH == 0, "prefetch depth must divide the ring size");
+	constexpr int DEPTH = PRE ? 4 : K1_DEPTH;   // rows in flight per wave; RING % DEPTH == 0 keeps the buffer roles static after unrolling
+	static_assert(RING % DEPTH == 0, "prefetch depth must divide the ring size");
 	uint32_t buf[DEPTH][12];          // row t lives in buf[t % DEPTH] and is refilled with row t+DEPTH as soon as it is consumed
-	if (!PRE) {
+	auto bounded = [&](int y) { return clampy(dir > 0 ? (y < y_stop ? y : y_stop) : (y > y_stop ? y : y_stop)); };
+	// PRE (sharpen): the row streamed at step t is the one AHEAD of the output row, reflect(yb(t) + dir) with yb = bounded(y):
+	// sharpened row yb needs gray rows yb-1, yb, yb+1, kept in a 4-slot ring GR (slot = step mod 4; 4 divides RING, so roles stay static)
+	auto ahead = [&](int t) {
+		const int a = bounded(y_first + dir * t) + dir;
+		return a < 0 ? 1 : (a >= IMG ? IMG - 2 : a);   // BORDER_REFLECT_101 of the sharpen filter
+	};
+	uint32_t GR[4][8];
+	if (PRE) {
+		static_assert(!PRE || RING % 4 == 0, "gray ring period must divide the box ring");
+		// slots 3 and 0 = the rows behind and at the first output row
+		const int y0 = clampy(y_first), yb = y0 - dir;
+		uint32_t d0[12], d1[12], T[16];
+		load_row48(row_ptr(frame, yb < 0 ? 1 : (yb >= IMG ? IMG - 2 : yb)), lane, d0);
+		load_row48(row_ptr(frame, y0), lane, d1);
+#pragma unroll
+		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, ahead(k)), lane, buf[k]);
+		gray16_T(d0, T); pairs_from_T(T, GR[3]);
+		gray16_T(d1, T); pairs_from_T(T, GR[0]);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { GR[1][i] = 0; GR[2][i] = 0; }
+	} else {
 #pragma unroll
 		for (int k = 0; k < DEPTH; ++k) load_row48(row_ptr(frame, clampy(y_first + dir * k)), lane, buf[k]);
 	}
@@ -271,7 +316,6 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 	// Straight-line body: every unrolled step runs unconditionally (rows past the strip are clamped re-reads whose results
 	// are never stored), so the refill of a consumed buffer is an unconditional load into the same registers -- no phi,
 	// no copy, and the compiler's vmcnt waits only ever cover the oldest row in flight.
-	auto bounded = [&](int y) { return clampy(dir > 0 ? (y < y_stop ? y : y_stop) : (y > y_stop ? y : y_stop)); };
 	for (int t0 = 0; t0 < total; t0 += RING) {
 #pragma unroll
 		for (int s = 0; s < RING; ++s) {
@@ -279,10 +323,19 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 			const int y = y_first + dir * t;
 			uint32_t (&d)[12] = buf[s % DEPTH];
 			uint32_t G[8];
+			int yl = y;   // the image row held in d
 			if (PRE) {
-				uint32_t g[16];
-				sharp_row(frame, bounded(y), lane, d, g);
-				pairs_from_g(g, G);
+				yl = ahead(t);
+				uint32_t T[16];
+				gray16_T(d, T);
+				pairs_from_T(T, GR[(s + 1) & 3]);
+				sharp_pairs(GR[(s + 3) & 3], GR[s & 3], GR[(s + 1) & 3], G);
+				if (bounded(y + dir) == bounded(y)) {
+					// the output row repeats (replicated border of the threshold source, or past the strip): re-seat the two
+					// rows behind so the next step sees the same neighbourhood. Only the image's first / last strip gets here.
+#pragma unroll
+					for (int i = 0; i < 8; ++i) { GR[(s + 1) & 3][i] = GR[s & 3][i]; GR[s & 3][i] = GR[(s + 3) & 3][i]; }
+				}
 			} else {
 				uint32_t T[16];
 				gray16_T(d, T);
@@ -290,8 +343,8 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 			}
 
 			// colour column sums: rows 9r+9 .. 9r+14 are the inner rows of cell row r (cell top = 8 + 9r)
-			const bool in_grid = y >= y_begin && y < y_end && y >= OFFSET + 1 && y < OFFSET + DIM * PITCH;
-			const int ph = in_grid ? (y - OFFSET) % PITCH : 0;
+			const bool in_grid = yl >= y_begin && yl < y_end && yl >= OFFSET + 1 && yl < OFFSET + DIM * PITCH;
+			const int ph = in_grid ? (yl - OFFSET) % PITCH : 0;
 			if (ph >= 1 && ph <= 6) {
 #pragma unroll
 				for (int k = 0; k < 12; ++k) {
@@ -299,7 +352,8 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 					acc_o[k] += __builtin_amdgcn_perm(0u, d[k], 0x0c030c01u);   // (d >> 8) & 0x00FF00FF in one op
 				}
 			}
-			if (!PRE) load_row48(row_ptr(frame, bounded(y + dir * DEPTH)), lane, d);   // d is dead: refill it with the row DEPTH steps ahead
+			// d is dead: refill it with the row DEPTH steps ahead
+			load_row48(row_ptr(frame, PRE ? ahead(t + DEPTH) : bounded(y + dir * DEPTH)), lane, d);
 
 			if (ph == (dir > 0 ? 6 : 1)) {   // the cell row's last inner row in walking order
 				uint16_t* sc = s_col[wave];
@@ -314,7 +368,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
-				const int cell_row = (y - OFFSET) / PITCH;
+				const int cell_row = (yl - OFFSET) / PITCH;
 #pragma unroll
 				for (int half = 0; half < 2; ++half) {
 					const int c = lane + 64 * half;

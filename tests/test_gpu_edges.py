@@ -50,7 +50,8 @@ def test_ragged_batch_sizes_and_capacity_changes(hip_decoder, synth, sizes):
 
 
 def test_degenerate_frames_match_oracle(hip_decoder):
-    """black, white, and pure-noise frames: nothing decodes, nothing crashes, every stage still equals the oracle
+    """black, white, and pure-noise frames: nothing crashes and every stage still equals the oracle (a black frame is all-zero RS
+    codewords, so the reference delivers some all-zero chunks from it; so must we)
     (noise drives every cell through the flood-order pass with saturated drift)."""
     rng = np.random.default_rng(9)
     frames = [np.zeros((1024, 1024, 3), np.uint8), np.full((1024, 1024, 3), 255, np.uint8),
@@ -91,7 +92,7 @@ def test_bad_arguments_are_refused(hip_decoder):
     # the context is still usable after refusals
     hip_decoder.reset_ccm()
     good, _, m = hip_decoder.decode_frame(buf)
-    assert good == 0 and m == 0
+    assert good == 625 * bin(m).count("1")   # (a black frame is all-zero RS codewords: the reference "decodes" some of it too)
 
 
 def test_unsupported_modes_and_devices_fail_loudly():
@@ -101,7 +102,8 @@ def test_unsupported_modes_and_devices_fail_loudly():
     with pytest.raises(D.CimbarHipError):
         D.HipDecoder(device=4096)
     d = D.HipDecoder(device=0, mode=0)   # 0 = the reference's default config == mode B
-    assert d.decode_frame(np.zeros((1024, 1024, 3), np.uint8))[0] == 0
+    good, _, m = d.decode_frame(np.full((1024, 1024, 3), 255, np.uint8))
+    assert good == 625 * bin(m).count("1")
 
 
 def test_tap_needs_a_decoded_batch():
