@@ -739,6 +739,15 @@ static void von_kries_ccm(const float white[3], float out[9])
 	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += tmp[i * 3 + k] * T[k * 3 + j]; out[i * 3 + j] = s; }
 }
 
+/* exported for the known-answer tests of chromatic_adaptation/test/color_correctionTest.cpp (values printed by a real OpenCV) */
+void co_moore_penrose_lsm(const float* actual, const float* desired, int rows, float out9[9]) { moore_penrose_lsm(actual, desired, rows, out9); }
+void co_von_kries_ccm(const float white[3], float out9[9]) { von_kries_ccm(white, out9); }
+/* color_correction.h:64-68 transform(): Matx33f * Vec3f, the same sums co_best_color applies */
+void co_ccm_transform(const float m[9], float r, float g, float b, float out3[3])
+{
+	for (int i = 0; i < 3; ++i) { float s = 0; s += m[i * 3] * r; s += m[i * 3 + 1] * g; s += m[i * 3 + 2] * b; out3[i] = s; }
+}
+
 /* ------------------------------------------------------------------------------------------------ fountain header */
 /* lib/fountain/FountainMetadata.h:16-92 */
 static uint32_t md_id(const uint8_t h[6]) { uint32_t v; memcpy(&v, h, 4); return v; }

@@ -7,8 +7,10 @@
  * oracle/Makefile into oracle/_ref/libcimbar_ref.so (tests/test_oracle_vs_ref.py), and against the reference's
  * known-answer vectors (tests/test_oracle_golden.py). The OpenCV primitives the reference calls (gray conversion,
  * box-mean threshold, filter2D, SVD pseudo-inverse) are NOT in /root/reference; both this file and the cv-shim the
- * reference is compiled against restate OpenCV 4.5.x's published arithmetic, so parity AT THE OPENCV BOUNDARY IS
- * UNPINNED (see DESIGN.md "Oracle").
+ * reference is compiled against restate OpenCV 4.5.x's published arithmetic. The SVD / pseudo-inverse / von Kries
+ * part of that is pinned to the matrices a real OpenCV printed in color_correctionTest.cpp:14-82; the per-pixel part
+ * (gray, box mean, filter2D, cv::mean) has no sample-free known-answer test in the reference, so parity AT THAT PART OF
+ * THE OPENCV BOUNDARY IS UNPINNED (see DESIGN.md "Oracle").
  */
 #ifndef CIMBAR_ORACLE_H
 #define CIMBAR_ORACLE_H
@@ -49,6 +51,11 @@ int co_rs_encode(const uint8_t* msg, unsigned msg_len, unsigned parity, uint8_t*
 
 /* CimbDecoder.cpp:168-200 */
 unsigned co_best_color(float r, float g, float b, const co_ccm* ccm);
+
+/* chromatic_adaptation/color_correction.h:26-39, :11-24, :64-68 -- exported for the reference's known-answer tests */
+void co_moore_penrose_lsm(const float* actual, const float* desired, int rows, float out9[9]);
+void co_von_kries_ccm(const float white[3], float out9[9]);
+void co_ccm_transform(const float m[9], float r, float g, float b, float out3[3]);
 
 /* Decoder::decode_fountain (Decoder.h:171-189) for one 1024x1024 RGB8 frame.
  * chunks: 12*625 bytes, slot j = fountain chunk j (zero-filled if dropped); *good_mask bit j = chunk j delivered.

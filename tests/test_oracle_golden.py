@@ -151,3 +151,39 @@ def test_rs_vectors_from_libcorrect(oracle):
         assert r == v["ret"], v["errors"]
         if r > 0:
             assert out.tobytes().hex() == v["decoded"]
+
+
+def _cvfmt(m):
+    """cv::Matx<float,3,3> through operator<< (OpenCV's default formatter prints floats with %.8g)."""
+    rows = [", ".join("%.8g" % float(v) for v in m[3 * i:3 * i + 3]) for i in range(3)]
+    return "[" + ";\n ".join(rows) + "]"
+
+
+def test_ccm_known_answers_printed_by_a_real_opencv(oracle):
+    # src/lib/chromatic_adaptation/test/color_correctionTest.cpp:14-82: the only matrices in the reference's tests that a real
+    # OpenCV (SVD::compute + backSubst + gemm, Matx arithmetic) computed. They pin the oracle's Jacobi-SVD / pseudo-inverse /
+    # von Kries restatement to the 8 digits the test prints.
+    import ctypes
+    F9, F3 = ctypes.c_float * 9, ctypes.c_float * 3
+    out = F9()
+    oracle.co_von_kries_ccm(F3(192, 255, 255), out)
+    assert _cvfmt(list(out)) == ("[1.0655777, 0.2109226, -0.013239831;\n"
+                                 " 0.023168325, 0.98723376, -0.0046780901;\n"
+                                 " 0, 0, 1]")
+    c = F3()
+    oracle.co_ccm_transform.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    oracle.co_ccm_transform(out, 180, 98, 255, c)
+    assert abs(c[0] - 209.09822971) < 1e-4 and abs(c[1] - 99.72629027) < 1e-4 and abs(c[2] - 255) < 1e-4
+
+    desired = [0, 255, 0, 0, 255, 255, 255, 255, 0, 255, 0, 255, 255, 255, 255]
+    cases = [
+        ([0, 142.31060606, 0, 0, 148.75, 148.75, 148.75, 148.75, 0, 148.75, 0, 148.75, 255, 255, 255],
+         "[1.5223049, -0.10023587, -0.19198087;\n -0.20533442, 1.6441474, -0.20533434;\n -0.19198078, -0.10023584, 1.5223049]"),
+        ([14.58901515, 115.74431818, 39.88320707, 19.34027778, 124.4375, 115.37152778, 140.70486111, 137.45833333, 65.50694444,
+          131.59722222, 41.22222222, 104.84027778, 171.625, 163.625, 158.875],
+         "[2.0261116, -0.21691091, -0.19806443;\n -0.43822661, 2.4562523, -0.41700464;\n -0.55769891, -1.1443435, 3.4819376]"),
+    ]
+    F15 = ctypes.c_float * 15
+    for actual, want in cases:
+        oracle.co_moore_penrose_lsm(F15(*actual), F15(*desired), 5, out)
+        assert _cvfmt(list(out)) == want
