@@ -15,6 +15,7 @@
 //   K3 k_rs             (colours: 20 blocks)
 //   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots, CCM carry-out
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cfloat>
 #include <cstdint>
@@ -61,7 +62,9 @@ __constant__ uint8_t c_gf_log[256];
 struct Tables {
 	ushort2* cell_xy;        // [NCELLS] top-left pixel of each cell (CellPositions.cpp:5-51)
 	uint16_t* stream_cell;   // [NCELLS] stream index -> linear cell index (Interleave.h:8-24)
-	int16_t* adj;            // [NCELLS][4] right, left, bottom, top (AdjacentCellFinder.cpp:16-105)
+	int16_t* cand;           // [NCELLS][12] the cells FloodDecodePositions::update may offer to, in its order: right, left, bottom,
+	                         // top (AdjacentCellFinder.cpp:16-105), then the 4 horizontal and 4 vertical "horizon" cells
+	                         // (FloodDecodePositions.cpp:93-129); -1 = none
 };
 
 // ------------------------------------------------------------------------------------------------ K1 threshold+pack
@@ -571,55 +574,168 @@ __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ pl
 }
 
 // ------------------------------------------------------------------------------------------------ K2b exact flood
-// FloodDecodePositions.cpp:17-134 + CimbReader.cpp:139-162 + CimbDecoder.cpp:101-147, literally, one wavefront per
-// flagged frame. The priority queue replays libstdc++'s push_heap/pop_heap (bits/stl_heap.h) so that equal-priority
-// cells pop in the same order as std::priority_queue; lane 0 owns the heap, all 64 lanes share the popcount work.
+// FloodDecodePositions.cpp:17-134 + CimbReader.cpp:139-162 + CimbDecoder.cpp:101-147, literally: the visiting order of the
+// reference's std::priority_queue decides which neighbour's drift a cell inherits, so the queue is replayed operation for
+// operation (libstdc++ bits/stl_heap.h push_heap / pop_heap, including how equal priorities fall) -- a serial algorithm.
+// One wavefront per flagged frame, everything it touches per step in LDS (the frame's bit plane, per-cell state, the heap),
+// and the 64 lanes cooperate inside every step:
+//   * heap pop: the walk down the tree fetches a whole 6-level subtree with one gather (lane l <- node r*2^d + l, d = depth
+//     of l in the subtree), picks children with v_readlane, and the libstdc++ "hole" shuffle becomes one scattered write;
+//   * heap push: the <=17 ancestors of the new slot are fetched with one gather, a ballot finds where the climb stops;
+//   * decode: the (window, tile) popcounts are spread over the lanes, DPP min-reduce;
+//   * the <=12 neighbour offers (4 adjacent + 8 "horizon") are evaluated one per lane from a precomputed candidate table.
+// A heap entry carries everything the reference keeps in _instructions[] for a cell (an accepted offer always has a
+// strictly smaller priority than the cell's previous ones, so the entry that pops first IS the latest instruction):
+//   prio(7) << 25 | cell(14) << 11 | dx+8 (4) << 7 | dy+8 (4) << 3 | cooldown code (3)
+// The eight seed cells are the exception (their seed entry pops with priority 0/1 but must use the latest accepted offer, if
+// any): their current instruction lives in s_seed[]. s_state[cell] (u16) = best offered priority + 1, 0x7FFF (no offer yet), or, once
+// visited, 0x8000 | symbol | dx+8 << 4 | dy+8 << 9 -- the results stay in LDS until the frame is done, so the only global
+// accesses inside the loop are the two prefetches.
+constexpr int HEAP_LDS = 10240;  // heap slots held in LDS (40 KiB; a clean shifted frame peaks near 9 200 live entries); deeper slots
+                                 // spill to the global scratch under the same indices
 struct FloodScratch {
-	uint32_t* heap;      // [F][HEAP_CAP]  (prio << 16) | idx ; ordering compares prio only
-	uint32_t* instr;     // [F][NCELLS]    dx+8 | (dy+8) << 8 | prio << 16 | cooldown << 24
-	uint8_t* remaining;  // [F][NCELLS]
+	uint32_t* heap;      // [F][HEAP_CAP], only indices >= HEAP_LDS are ever touched
 };
 
-__device__ __forceinline__ void heap_sift_up(uint32_t* h, int hole, int top, uint32_t value)
-{
-	int parent = (hole - 1) / 2;
-	while (hole > top && (h[parent] >> 16) > (value >> 16)) {
-		h[hole] = h[parent];
-		hole = parent;
-		parent = (hole - 1) / 2;
+__device__ __forceinline__ uint32_t cool_enc(uint32_t c) { return c == 0xFEu ? 0u : (c == 0xFFu ? 2u : c); }   // real values: 1,3,4,5,7
+__device__ __forceinline__ uint32_t cool_dec(uint32_t k) { return k == 0u ? 0xFEu : (k == 2u ? 0xFFu : k); }
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// The spill half of the heap (slots >= HEAP_LDS, global memory), only compiled into the SPILL = true instance of a step
+// (taken when the heap is within a step's growth of HEAP_LDS). Out of line on purpose: it is cold, and inlined the compiler
+// would have to assume pending global loads around every heap access.
+__device__ __attribute__((noinline)) uint32_t heap_spill_get(const uint32_t* g, int i, uint32_t v) { return i >= HEAP_LDS ? g[i] : v; }
+__device__ __attribute__((noinline)) void heap_spill_set(uint32_t* g, int i, uint32_t v, bool on) { if (on && i >= HEAP_LDS) g[i] = v; }
+
+struct PopPrefetch { uint32_t value, v, vl, vr; };
+
+struct WaveHeap {
+	lds_u32* lds;
+	uint32_t* glob;
+	int n;
+	// i, on: per lane. Reads are unconditional (a masked-off lane reads slot 0) so that they cost no branch.
+	template <bool SPILL>
+	__device__ __forceinline__ uint32_t get(int i, bool on = true) const
+	{
+		uint32_t v = lds[(on && i < HEAP_LDS) ? i : 0];
+		if constexpr (SPILL) v = heap_spill_get(glob, on ? i : 0, v);
+		return v;
 	}
-	h[hole] = value;
-}
-__device__ __forceinline__ void heap_push(uint32_t* h, int& n, uint32_t e)
-{
-	h[n] = e;
-	++n;
-	heap_sift_up(h, n - 1, 0, e);
-}
-__device__ __forceinline__ uint32_t heap_pop(uint32_t* h, int& n)
-{
-	uint32_t top = h[0];
-	if (n > 1) {
-		int len = n - 1;
-		uint32_t value = h[len];
-		h[len] = top;
-		int hole = 0, second = 0;
-		while (second < (len - 1) / 2) {
-			second = 2 * (second + 1);
-			if ((h[second] >> 16) > (h[second - 1] >> 16)) second--;
-			h[hole] = h[second];
-			hole = second;
-		}
-		if ((len & 1) == 0 && second == (len - 2) / 2) {
-			second = 2 * (second + 1);
-			h[hole] = h[second - 1];
-			hole = second - 1;
-		}
-		heap_sift_up(h, hole, 0, value);
+	template <bool SPILL>
+	__device__ __forceinline__ void set(int i, uint32_t v, bool on) const
+	{
+		if (on && i < HEAP_LDS) lds[i] = v;
+		if constexpr (SPILL) heap_spill_set(glob, i, v, on);
 	}
-	--n;
-	return top;
-}
+
+	// std::push_heap after push_back (stl_heap.h __push_heap): climb while the parent's priority is greater
+	template <bool SPILL>
+	__device__ __forceinline__ void push(uint32_t e, int lane)
+	{
+		const int pos = n++;
+		const int depth = 31 - __builtin_clz((unsigned)pos + 1u);        // ancestors a_1 .. a_depth (= root)
+		const int a = (int)(((unsigned)pos + 1u) >> (lane < 31 ? lane : 31)) - 1;   // a_0 = pos
+		const bool anc = lane >= 1 && lane <= depth;
+		const uint32_t v = get<SPILL>(a, anc);
+		const unsigned long long stop = __ballot(anc && !((v >> 25) > (e >> 25)));
+		const int m = stop ? (int)__builtin_ctzll(stop) - 1 : depth;   // the new element lands in a_m
+		const uint32_t vnext = from_right_lane(v, 0u);                   // lane k <- H[a_{k+1}]
+		set<SPILL>(a, lane < m ? vnext : e, lane <= m);
+	}
+
+	// what pop() reads first, so that it can be requested together with the peek at the top
+	template <bool SPILL>
+	__device__ __forceinline__ PopPrefetch prefetch(int lane) const
+	{
+		const int len = n - 1, half = (len - 1) / 2;
+		PopPrefetch p;
+		p.value = get<SPILL>(len > 0 ? len : 0);
+		p.v = get<SPILL>(lane, lane < 63 && lane < len);
+		const bool inner = lane < 31 && lane < half;
+		p.vl = get<SPILL>(2 * lane + 1, inner);
+		p.vr = get<SPILL>(2 * lane + 2, inner);
+		return p;
+	}
+
+	// std::pop_heap + pop_back (stl_heap.h __pop_heap -> __adjust_heap -> __push_heap); the caller has read the top already.
+	// __adjust_heap walks the hole from the root to the bottom, always into the child the comparator prefers (the right one on
+	// ties), moving that child up; __push_heap then lifts the old last element `value` back up over the moved elements. In
+	// terms of the OLD array and the path c_0 = root, c_1, .., c_L: with j = the deepest k >= 1 whose H[c_k] has priority <=
+	// value's (0 if none), H[c_{k-1}] <- H[c_k] for k <= j, H[c_j] <- value, everything else stays.
+	// The walk takes five levels per LDS round trip: lane l fetches node l of the 63-node subtree under the hole (global
+	// index hole*2^d + l, d = depth of l) and, if it is an inner node, its two children; a ballot turns the comparisons into
+	// one bit per node and the descent is five scalar bit-lookups.
+	template <bool SPILL>
+	__device__ __forceinline__ void pop(int lane, const PopPrefetch& pf)
+	{
+		const int len = n - 1;                  // elements that remain; `value` = the old last one, re-inserted from the root
+		if (len == 0) { n = 0; return; }
+		const uint32_t value = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf.value);
+		const uint32_t vprio = value >> 25;
+		const int half = (len - 1) / 2;         // nodes below this index have two children
+		const int d = 31 - __builtin_clz((unsigned)lane + 1u);
+		uint32_t bv[4];
+		int bg[4];
+		bool bp[4];
+		int S = 1, depth = 0, j = 0;            // 1-based index of the hole, its depth, and the j of the comment above
+#pragma unroll
+		for (int B = 0; B < 4; ++B) {
+			bv[B] = 0; bg[B] = 0; bp[B] = false;
+			if (S - 1 < half) {
+				const int gi = ((S - 1) << d) + lane;
+				const bool inner = lane < 31 && gi < half;
+				uint32_t v, vl, vr;
+				if (B == 0) { v = pf.v; vl = pf.vl; vr = pf.vr; }
+				else {
+					v = get<SPILL>(gi, lane < 63 && gi < len);
+					vl = get<SPILL>(2 * gi + 1, inner);
+					vr = get<SPILL>(2 * gi + 2, inner);
+				}
+				// comp(first[second], first[second-1]) -> second-- : the left child only if the right one's priority is greater
+				const unsigned long long right = __ballot(inner && !((vr >> 25) > (vl >> 25)));
+				unsigned long long pm = 0;
+				int m = 1;                            // 1-based local node
+#pragma unroll
+				for (int lev = 0; lev < 5; ++lev) {
+					if (S - 1 < half) {
+						const int t = (int)((right >> (m - 1)) & 1ull);
+						m = 2 * m + t;
+						S = 2 * S + t;
+						++depth;
+						pm |= 1ull << (m - 1);
+					}
+				}
+				const bool onpath = (pm >> lane) & 1ull;
+				bv[B] = v; bg[B] = gi; bp[B] = onpath;
+				const unsigned long long cm = __ballot(onpath && (v >> 25) <= vprio);
+				if (cm) j = 5 * B + (31 - __builtin_clz((unsigned)(63 - (int)__builtin_clzll(cm)) + 1u));
+			}
+		}
+		// (four blocks cover 20 levels; HEAP_CAP < 2^18)
+		int tail = -1;                              // a last node with a left child only
+		uint32_t tailv = 0;
+		if ((len & 1) == 0 && S - 1 == (len - 2) / 2) {
+			tail = 2 * (S - 1) + 1;
+			tailv = (uint32_t)__builtin_amdgcn_readfirstlane((int)get<SPILL>(tail));
+			++depth;
+			if ((tailv >> 25) <= vprio) j = depth;
+		}
+#pragma unroll
+		for (int B = 0; B < 4; ++B) {
+			if (B == 0 || 5 * B < depth) {
+				const int dp = 5 * B + d;
+				set<SPILL>((bg[B] - 1) >> 1, bv[B], bp[B] && dp <= j);
+				set<SPILL>(bg[B], value, bp[B] && dp == j);
+			}
+		}
+		if (tail >= 0 && j == depth) {
+			set<SPILL>((tail - 1) >> 1, tailv, lane == 0);
+			set<SPILL>(tail, value, lane == 0);
+		}
+		if (j == 0) set<SPILL>(0, value, lane == 0);
+		n = len;
+	}
+};
 
 __device__ __forceinline__ uint32_t calc_cooldown(uint32_t previous, uint32_t idx)
 {
@@ -630,131 +746,220 @@ __device__ __forceinline__ uint32_t calc_cooldown(uint32_t previous, uint32_t id
 	return idx;
 }
 
-__device__ __forceinline__ void offer(int next, uint32_t* h, int& hn, uint32_t* instr, const uint8_t* remaining, int dx, int dy,
-                                      uint32_t dist, uint32_t cooldown)
+// minimum of a 32-bit value over the wave (uniform result)
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
 {
-	// FloodDecodePositions.cpp:69-83 update_adjacents, one neighbour
-	if (next < 0 || !remaining[next]) return;
-	uint32_t di = instr[next];
-	if (((di >> 16) & 0xFF) <= dist) return;
-	instr[next] = (uint32_t)(dx + 8) | ((uint32_t)(dy + 8) << 8) | ((dist & 0xFF) << 16) | (cooldown << 24);
-	heap_push(h, hn, ((dist & 0xFF) << 16) | (uint32_t)next);
+	uint32_t o;
+	o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); v = o < v ? o : v;    // quad_perm:[1,0,3,2]
+	o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); v = o < v ? o : v;    // quad_perm:[2,3,0,1]
+	o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); v = o < v ? o : v;   // row_half_mirror
+	o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); v = o < v ? o : v;   // row_mirror
+	const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+	const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+	const uint32_t ab = a < b ? a : b, ce = c < e ? c : e;
+	return ab < ce ? ab : ce;
 }
 
+// FloodDecodePositions.cpp:27-41, in push order; -1 for everything else. All eight sit in the first 712 or last 712 cells.
+__device__ __forceinline__ int seed_slot(int i)
+{
+	if ((unsigned)(i - (TOP_CELLS + DIM)) < (unsigned)(NCELLS - 2 * (TOP_CELLS + DIM))) return -1;
+	int s = -1;
+	s = i == 0 ? 0 : s;
+	s = i == TOP_W - 1 ? 1 : s;
+	s = i == NCELLS - 1 ? 2 : s;
+	s = i == NCELLS - TOP_W ? 3 : s;
+	s = i == TOP_CELLS ? 4 : s;
+	s = i == TOP_CELLS + DIM - 1 ? 5 : s;
+	s = i == NCELLS - 1 - TOP_CELLS ? 6 : s;
+	s = i == NCELLS - TOP_CELLS - DIM ? 7 : s;
+	return s;
+}
+
+constexpr int FLOOD_GRID = 512;   // state + heap = 65 KiB of LDS: two workgroups per CU
 __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane, Tables tb, FloodScratch sc,
                                               const uint32_t* __restrict__ flood_flag, uint8_t* __restrict__ symbols,
-                                              int8_t* __restrict__ drift, uint8_t* __restrict__ dist_out, int f0)
+                                              int8_t* __restrict__ drift, int f0, int nframes)
 {
-	const int f = f0 + blockIdx.x, lane = threadIdx.x;
-	if (!flood_flag[f]) return;
-	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
-	uint32_t* h = sc.heap + (size_t)f * HEAP_CAP;
-	uint32_t* instr = sc.instr + (size_t)f * NCELLS;
-	uint8_t* remaining = sc.remaining + (size_t)f * NCELLS;
+	__shared__ __attribute__((aligned(16))) uint16_t s_state[NCELLS + 8];
+	__shared__ uint32_t s_heap[HEAP_LDS];
+	__shared__ uint32_t s_seed[8];                                           // prio << 16 | (dx+8) << 7 | (dy+8) << 3 | cooldown code
+	const int lane = threadIdx.x;
+	constexpr uint32_t DEFAULT_D = (8u << 7) | (8u << 3) | 0u;              // CellDrift(), cooldown 0xFE
 
-	for (int i = lane; i < NCELLS; i += 64) { instr[i] = 8u | (8u << 8) | (0xFEu << 16) | (0xFEu << 24); remaining[i] = 1; }
-	__syncthreads();
+	for (int fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
+		const int f = f0 + fi;
+		if (!flood_flag[f]) continue;
+		const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
+		__syncthreads();   // the previous frame of this workgroup is completely done with the LDS
+		{
+			uint4 ff; ff.x = ff.y = ff.z = ff.w = 0x7FFF7FFFu;
+			for (int i = lane; i < (NCELLS + 8) / 8; i += 64) reinterpret_cast<uint4*>(s_state)[i] = ff;
+			if (lane < 8) s_seed[lane] = (0xFEu << 16) | DEFAULT_D;
+		}
+		WaveHeap hp{(lds_u32*)s_heap, sc.heap + (size_t)f * HEAP_CAP, 0};
+		__syncthreads();
+		{
+			const uint32_t last = NCELLS - 1;
+			auto seed = [&](uint32_t prio, uint32_t cell) { hp.push<false>((prio << 25) | (cell << 11) | DEFAULT_D, lane); };
+			seed(0, 0u); seed(0, (uint32_t)(TOP_W - 1)); seed(0, last); seed(0, last - (TOP_W - 1));
+			seed(1, (uint32_t)TOP_CELLS); seed(1, (uint32_t)(TOP_CELLS + DIM - 1)); seed(1, last - TOP_CELLS); seed(1, last - (TOP_CELLS + DIM - 1));
+		}
 
-	__shared__ int s_cell;
-	__shared__ int s_hn;
-	if (lane == 0) {
-		int hn = 0;
-		const uint32_t last = NCELLS - 1;
-		heap_push(h, hn, 0u);
-		heap_push(h, hn, (uint32_t)(TOP_W - 1));
-		heap_push(h, hn, last);
-		heap_push(h, hn, last - (TOP_W - 1));
-		heap_push(h, hn, (1u << 16) | (uint32_t)TOP_CELLS);
-		heap_push(h, hn, (1u << 16) | (uint32_t)(TOP_CELLS + DIM - 1));
-		heap_push(h, hn, (1u << 16) | (last - TOP_CELLS));
-		heap_push(h, hn, (1u << 16) | (last - (TOP_CELLS + DIM - 1)));
-		s_hn = hn;
-	}
-	__syncthreads();
-
-	const int ORDER[9] = {4, 5, 7, 3, 1, 8, 0, 2, 6};   // ahash_result.h:26
-	for (int count = 0; count < NCELLS; ++count) {
-		if (lane == 0) {
-			int hn = s_hn, cell = -1;
-			while (hn > 0) {                                   // FloodDecodePositions.cpp:49-67 next()
-				uint32_t e = heap_pop(h, hn);
-				int idx = (int)(e & 0xFFFFu);
-				if (!remaining[idx]) continue;
-				remaining[idx] = 0;
-				cell = idx;
+		constexpr uint32_t ORDER8 = 0x20813754u;   // nibble k = k-th window visited: 4,5,7,3,1,8,0,2 and then 6 (ahash_result.h:26)
+		const uint64_t my_tile = c_tile[lane & 15];
+		// lanes 0..8 each build the 8x8 hash of window w = lane out of the ten 10-bit rows (bit_extractor.h:23-51)
+		const int hw = lane < 9 ? lane : 0;
+		const uint32_t h_cs = 2u - (uint32_t)(hw % 3), h_r8 = 8u * (uint32_t)(hw / 3);
+#ifdef FLOOD_PROF
+		unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc0;
+#define PROF_T0() pc0 = __builtin_readcyclecounter()
+#define PROF_ADD(k) do { unsigned long long pc1 = __builtin_readcyclecounter(); pt[k] += pc1 - pc0; pc0 = pc1; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(k)
+#endif
+		// one step = one decoded cell; instantiated without and with the heap's spill half
+		auto step = [&](auto spill_tag) __attribute__((always_inline)) -> bool {
+			constexpr bool SPILL = decltype(spill_tag)::value;
+			PROF_T0();
+			// ---- FloodDecodePositions::next(): pop until a cell that still needs decoding turns up. The top of the heap names
+			// the cell, and (with s_seed) where its window is, before the pop has run: the twenty bit-plane words of the
+			// window and the cell's offer list are requested from L2 first and arrive behind the pop.
+			int i = -1;
+			uint32_t e = 0, di = 0, prev_prio = 0, pw = 0, sh = 0;
+			int16_t cand = -1;
+			while (hp.n > 0) {
+				const uint32_t topv = hp.get<SPILL>(0);
+				const PopPrefetch pf = hp.prefetch<SPILL>(lane);   // same LDS round trip as the peek
+				e = (uint32_t)__builtin_amdgcn_readfirstlane((int)topv);
+				PROF_ADD(7);
+				const int idx = (int)((e >> 11) & 0x3FFFu);
+				const bool fresh = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_state[idx]) & 0x8000u) == 0;
+				if (fresh) {
+					di = e & 0x7FFu; prev_prio = e >> 25;
+					const int slot = seed_slot(idx);
+					if (slot >= 0) { const uint32_t sv = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_seed[slot]); di = sv & 0x7FFu; prev_prio = sv >> 16; }
+					// CellPositions.cpp:5-51 (the three bands of mode B)
+					int cx, cy;
+					if (idx < TOP_CELLS) { cx = OFFSET + (MARKER + idx % TOP_W) * PITCH; cy = OFFSET + (idx / TOP_W) * PITCH; }
+					else if (idx < TOP_CELLS + MID_CELLS) { const int q = idx - TOP_CELLS; cx = OFFSET + (q % DIM) * PITCH; cy = OFFSET + (MARKER + q / DIM) * PITCH; }
+					else { const int q = idx - TOP_CELLS - MID_CELLS; cx = OFFSET + (MARKER + q % TOP_W) * PITCH; cy = OFFSET + (DIM - MARKER + q / TOP_W) * PITCH; }
+					const int x0 = cx + (int)(di >> 7) - 9, y0 = cy + (int)((di >> 3) & 15u) - 9;   // top-left of the 10x10 window
+					const int j = x0 >> 5, j1 = j + 1 > 31 ? 31 : j + 1;   // j == 31: the window ends inside word 31
+					sh = 54u - (uint32_t)(x0 & 31);
+					// lane 2r: first word of window row r, lane 2r+1: the next word
+					if (lane < 20) pw = pl[(y0 + (lane >> 1)) * 32 + ((lane & 1) ? j1 : j)];
+					if (lane < 12) cand = tb.cand[(size_t)idx * 12 + lane];
+				}
+				PROF_ADD(8);
+				hp.pop<SPILL>(lane, pf);
+#ifdef FLOOD_PROF
+				pt[4] += 1;
+				if ((unsigned long long)hp.n > pt[6]) pt[6] = hp.n;
+#endif
+				if (!fresh) continue;
+				i = idx;
 				break;
 			}
-			s_hn = hn;
-			s_cell = cell;
-		}
-		__syncthreads();
-		const int i = s_cell;
-		if (i < 0) break;
+			if (i < 0) return false;
+			PROF_ADD(0);
+			const int ddx = (int)(di >> 7) - 8, ddy = (int)((di >> 3) & 15u) - 8;
+			const uint32_t cooldown = cool_dec(di & 7u);
 
-		const uint32_t di = instr[i];
-		const int ddx = (int)(di & 0xFF) - 8, ddy = (int)((di >> 8) & 0xFF) - 8;
-		const uint32_t prev_prio = (di >> 16) & 0xFF, cooldown = di >> 24;
-		ushort2 xy = tb.cell_xy[i];
-		const int x = (int)xy.x + ddx, y = (int)xy.y + ddy;
-
-		uint32_t rows[10];
-		window_rows(pl, x - 1, y - 1, rows);
-
-		// (window position k in visiting order, tile t) pairs over the lanes; key = dist << 8 | k << 4 | t, min wins
-		const int nwin = (cooldown == 0xFE) ? 9 : 5;         // CimbDecoder.cpp:144
-		const int t = lane & 15;
-		uint32_t best = 0xFFFFFFFFu;
-		for (int k = lane >> 4; k < nwin; k += 4) {
-			int w = ORDER[k];
-			if ((uint32_t)w == cooldown && w != 4) continue;   // CimbDecoder.cpp:114-115
-			uint32_t d = (uint32_t)__popcll(window_hash(rows, w) ^ c_tile[t]);
-			uint32_t key = (d << 8) | ((uint32_t)k << 4) | (uint32_t)t;
-			best = key < best ? key : best;
-		}
+			// even lanes < 20 form their 10-bit row (MSB = leftmost pixel); the rows become wave-uniform through readlane, and
+			// lane w < 9 assembles window w's hash: byte k = bits [cs, cs+8) of row r0+k, r0 = w/3, cs = 2 - w%3
+			//   -> the 10 bytes packed big-endian, cut at byte r0
+			uint32_t hlo, hhi;
+			{
+				const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pw, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]: lane^1
+				const uint32_t row = (uint32_t)((((uint64_t)pw << 32) | nxt) >> sh);
+				uint32_t tb_[10];
 #pragma unroll
-		for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(best, off); best = o < best ? o : best; }
+				for (int r = 0; r < 10; ++r) tb_[r] = ((uint32_t)__builtin_amdgcn_readlane((int)row, 2 * r) >> h_cs) & 0xFFu;
+				const uint32_t W0 = (tb_[0] << 24) | (tb_[1] << 16) | (tb_[2] << 8) | tb_[3];
+				const uint32_t W1 = (tb_[4] << 24) | (tb_[5] << 16) | (tb_[6] << 8) | tb_[7];
+				const uint32_t W2 = (tb_[8] << 24) | (tb_[9] << 16);
+				const uint64_t A = (((uint64_t)W0 << 32) | W1) << h_r8;
+				hhi = (uint32_t)(A >> 32);
+				hlo = (uint32_t)A | ((W2 >> 16) >> (16u - h_r8));
+			}
 
-		if (lane == 0) {
-			const uint32_t error_distance = best >> 8, w = (uint32_t)ORDER[(best >> 4) & 15], bits = best & 15u;
+			// (window position k in visiting order, tile t) pairs over the lanes; key = dist << 8 | k << 4 | t, min wins
+			const int nwin = (cooldown == 0xFEu) ? 9 : 5;         // CimbDecoder.cpp:144
+			uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+			for (int it = 0; it < 3; ++it) {
+				if (it * 4 >= nwin) break;
+				const int k = (lane >> 4) + 4 * it;
+				const uint32_t w = k < 8 ? (ORDER8 >> (4 * k)) & 15u : 6u;
+				const uint32_t wlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)hlo);
+				const uint32_t whi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)hhi);
+				const bool skip = k >= nwin || (w == cooldown && w != 4u);   // CimbDecoder.cpp:114-115
+				const uint32_t d = (uint32_t)__popc(wlo ^ (uint32_t)my_tile) + (uint32_t)__popc(whi ^ (uint32_t)(my_tile >> 32));
+				const uint32_t key = skip ? 0xFFFFFFFFu : ((d << 8) | ((uint32_t)k << 4) | (uint32_t)(lane & 15));
+				best = key < best ? key : best;
+			}
+			best = wave_min(best);
+			PROF_ADD(1);
+
+			const uint32_t kbest = (best >> 4) & 15u;
+			const uint32_t error_distance = best >> 8, w = kbest < 8 ? (ORDER8 >> (4 * kbest)) & 15u : 6u, bits = best & 15u;
 			const int bdx = (int)(w % 3) - 1, bdy = (int)(w / 3) - 1;                 // CellDrift.h:13-15
 			int ndx = ddx + bdx, ndy = ddy + bdy;                                     // CellDrift.cpp:23-31
 			ndx = ndx > 7 ? 7 : (ndx < -7 ? -7 : ndx);
 			ndy = ndy > 7 ? 7 : (ndy < -7 ? -7 : ndy);
 			const uint32_t ncool = calc_cooldown(cooldown, w);
+			// visited: the symbol and the position the colour pass reads (CimbReader.cpp:158-160 pos.x/y), each offset in [-8, 8]
+			if (lane == 0) s_state[i] = (uint16_t)(0x8000u | bits | ((uint32_t)(ddx + bdx + 8) << 4) | ((uint32_t)(ddy + bdy + 8) << 9));
 
-			symbols[(size_t)f * NCELLS + i] = (uint8_t)bits;
-			drift[((size_t)f * NCELLS + i) * 2] = (int8_t)(ddx + bdx);                // CimbReader.cpp:158-160 pos.x/y
-			drift[((size_t)f * NCELLS + i) * 2 + 1] = (int8_t)(ddy + bdy);
-			if (dist_out) dist_out[(size_t)f * NCELLS + i] = (uint8_t)error_distance;
-
-			int hn = s_hn;
-			const int16_t* adj = tb.adj + (size_t)i * 4;
-			const int ar = adj[0], al = adj[1], ab = adj[2], at = adj[3];
-			offer(ar, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);   // FloodDecodePositions.cpp:85-88
-			offer(al, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-			offer(ab, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-			offer(at, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-			if (prev_prio < 3 && error_distance < 3 && cooldown == 4 && ncool == 4) {   // :93-129 "horizon"
-				if (ar >= 0 && al >= 0) {
-					int h0 = tb.adj[(size_t)ar * 4 + 0], h1 = h0 >= 0 ? tb.adj[(size_t)h0 * 4 + 0] : -1;
-					int h2 = tb.adj[(size_t)al * 4 + 1], h3 = h2 >= 0 ? tb.adj[(size_t)h2 * 4 + 1] : -1;
-					offer(h0, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(h1, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(h2, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(h3, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-				}
-				if (at >= 0 && ab >= 0) {
-					int v0 = tb.adj[(size_t)at * 4 + 3], v1 = v0 >= 0 ? tb.adj[(size_t)v0 * 4 + 3] : -1;
-					int v2 = tb.adj[(size_t)ab * 4 + 2], v3 = v2 >= 0 ? tb.adj[(size_t)v2 * 4 + 2] : -1;
-					offer(v0, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(v1, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(v2, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-					offer(v3, h, hn, instr, remaining, ndx, ndy, error_distance, ncool);
-				}
+			// ---- FloodDecodePositions::update(): lanes 0-3 the adjacent cells (right, left, bottom, top), 4-7 the horizontal
+			// "horizon" (:93-111), 8-11 the vertical one (:113-129), in the reference's offer order. No cell occurs twice in
+			// one list (checked when the table is built), so the twelve update_adjacents checks are independent.
+			const unsigned long long have = __ballot(cand >= 0);
+			const bool far = prev_prio < 3 && error_distance < 3 && cooldown == 4 && ncool == 4;
+			const uint32_t lanes_ok = 0xFu | (far && (have & 3ull) == 3ull ? 0xF0u : 0u) | (far && (have & 12ull) == 12ull ? 0xF00u : 0u);
+			const bool want = lane < 12 && ((lanes_ok >> (lane & 15)) & 1u) && cand >= 0;
+			// update_adjacents (:69-83): still to decode and strictly better than what the cell was offered before
+			const uint32_t cst = s_state[want ? (int)cand : 0];
+			const bool accept = want && !(cst & 0x8000u) && cst >= error_distance + 2u;
+			const uint32_t dcode = ((uint32_t)(ndx + 8) << 7) | ((uint32_t)(ndy + 8) << 3) | cool_enc(ncool);
+			if (accept) {
+				s_state[cand] = (uint16_t)(error_distance + 1u);
+				const int sl = seed_slot((int)cand);
+				if (sl >= 0) s_seed[sl] = (error_distance << 16) | dcode;
 			}
-			s_hn = hn;
+			unsigned long long acc = __ballot(accept);
+			PROF_ADD(2);
+			while (acc) {
+				const int q = (int)__builtin_ctzll(acc);
+				acc &= acc - 1;
+				const uint32_t cell = (uint32_t)__builtin_amdgcn_readlane((int)cand, q);
+				hp.push<SPILL>((error_distance << 25) | (cell << 11) | dcode, lane);
+#ifdef FLOOD_PROF
+				pt[5] += 1;
+#endif
+			}
+			PROF_ADD(3);
+			return true;
+		};
+		for (int count = 0; count < NCELLS; ++count) {
+			// a step pushes at most 12 entries: below that margin no heap index can reach the spill half
+			const bool more = hp.n + 16 <= HEAP_LDS ? step(std::false_type{}) : step(std::true_type{});
+			if (!more) break;
 		}
+#ifdef FLOOD_PROF
+		if (lane == 0) for (int k = 0; k < 10; ++k) { sc.heap[(size_t)f * HEAP_CAP + 2 * k] = (uint32_t)pt[k]; sc.heap[(size_t)f * HEAP_CAP + 2 * k + 1] = (uint32_t)(pt[k] >> 32); }
+#endif
+		// results of the cells that were visited (all of them, unless the grid were disconnected)
 		__syncthreads();
+		for (int c = lane; c < NCELLS; c += 64) {
+			const uint32_t v = s_state[c];
+			if (!(v & 0x8000u)) continue;
+			symbols[(size_t)f * NCELLS + c] = (uint8_t)(v & 15u);
+			drift[((size_t)f * NCELLS + c) * 2] = (int8_t)((int)((v >> 4) & 31u) - 8);
+			drift[((size_t)f * NCELLS + c) * 2 + 1] = (int8_t)((int)((v >> 9) & 31u) - 8);
+		}
 	}
 }
 
@@ -1631,13 +1836,28 @@ int build_tables(cimbar_hip_ctx* ctx)
 	for (int part = 0; part < NCELLS; part += part_size)
 		for (int chunk = 0; chunk < RS_BLOCK; ++chunk)
 			for (int i = chunk; i < part_size; i += RS_BLOCK) sc.push_back((uint16_t)(i + part));
-	std::vector<int16_t> adj((size_t)NCELLS * 4);
+	// FloodDecodePositions::update's offer list per cell (FloodDecodePositions.cpp:85-129): adjacents, then both horizons
+	std::vector<int16_t> cand((size_t)NCELLS * 12);
 	AdjFinder finder{xy};
 	for (int i = 0; i < NCELLS; ++i) {
-		adj[(size_t)i * 4 + 0] = (int16_t)finder.right(i);
-		adj[(size_t)i * 4 + 1] = (int16_t)finder.left(i);
-		adj[(size_t)i * 4 + 2] = (int16_t)finder.bottom(i);
-		adj[(size_t)i * 4 + 3] = (int16_t)finder.top(i);
+		int16_t* c = &cand[(size_t)i * 12];
+		const int rr = finder.right(i), ll = finder.left(i), dd = finder.bottom(i), uu = finder.top(i);
+		c[0] = (int16_t)rr; c[1] = (int16_t)ll; c[2] = (int16_t)dd; c[3] = (int16_t)uu;
+		for (int k = 4; k < 12; ++k) c[k] = -1;
+		if (rr >= 0 && ll >= 0) {
+			const int h0 = finder.right(rr), h2 = finder.left(ll);
+			c[4] = (int16_t)h0; c[5] = (int16_t)(h0 >= 0 ? finder.right(h0) : -1);
+			c[6] = (int16_t)h2; c[7] = (int16_t)(h2 >= 0 ? finder.left(h2) : -1);
+		}
+		if (uu >= 0 && dd >= 0) {
+			const int v0 = finder.top(uu), v2 = finder.bottom(dd);
+			c[8] = (int16_t)v0; c[9] = (int16_t)(v0 >= 0 ? finder.top(v0) : -1);
+			c[10] = (int16_t)v2; c[11] = (int16_t)(v2 >= 0 ? finder.bottom(v2) : -1);
+		}
+		// k_flood evaluates the twelve offers of a step independently: that needs them to be distinct cells
+		for (int a = 0; a < 12; ++a)
+			for (int b = a + 1; b < 12; ++b)
+				if (c[a] >= 0 && c[a] == c[b]) { ctx->err = "build_tables: duplicate cell in a flood offer list"; return CIMBAR_HIP_EINVAL; }
 	}
 	// GF(2^8) tables, libcorrect field.h:26-62 with primitive polynomial 0x187 (correct.h:159-160)
 	uint8_t gexp[512], glog[256];
@@ -1651,10 +1871,10 @@ int build_tables(cimbar_hip_ctx* ctx)
 	}
 	HIPCHK(hipMalloc(&ctx->tb.cell_xy, sizeof(ushort2) * NCELLS));
 	HIPCHK(hipMalloc(&ctx->tb.stream_cell, sizeof(uint16_t) * NCELLS));
-	HIPCHK(hipMalloc(&ctx->tb.adj, sizeof(int16_t) * NCELLS * 4));
+	HIPCHK(hipMalloc(&ctx->tb.cand, sizeof(int16_t) * NCELLS * 12));
 	HIPCHK(hipMemcpy(ctx->tb.cell_xy, xy.data(), sizeof(ushort2) * NCELLS, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(ctx->tb.stream_cell, sc.data(), sizeof(uint16_t) * NCELLS, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(ctx->tb.adj, adj.data(), sizeof(int16_t) * NCELLS * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ctx->tb.cand, cand.data(), sizeof(int16_t) * NCELLS * 12, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_exp), gexp, 512));
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_gf_log), glog, 256));
 	// generator polynomial prod_{i=1..30} (x + alpha^i), low -> high (libcorrect reed-solomon.c:5-12, polynomial.c:205-240)
@@ -1697,8 +1917,6 @@ int ensure_capacity(cimbar_hip_ctx* ctx, int n)
 	HIPCHK(regrow(ctx->d_chunks, N * FRAME_BYTES));
 	HIPCHK(regrow(ctx->d_masks, N));
 	HIPCHK(regrow(ctx->flood.heap, N * HEAP_CAP));
-	HIPCHK(regrow(ctx->flood.instr, N * NCELLS));
-	HIPCHK(regrow(ctx->flood.remaining, N * NCELLS));
 	ctx->cap = n;
 	return 0;
 }
@@ -1708,10 +1926,10 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	auto fr = [](void* p) { if (p) (void)hipFree(p); };
-	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.adj);
+	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.cand);
 	fr(ctx->d_template); fr(ctx->d_gen_log); fr(ctx->d_payload); fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
 	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
-	fr(ctx->d_masks); fr(ctx->flood.heap); fr(ctx->flood.instr); fr(ctx->flood.remaining);
+	fr(ctx->d_masks); fr(ctx->flood.heap);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1735,7 +1953,8 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_flood, dim3(n), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols, ctx->d_drift, ctx->d_dist, f0);
+	hipLaunchKernelGGL(k_flood, dim3(n < FLOOD_GRID ? n : FLOOD_GRID), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
+	                   ctx->d_drift, f0, n);
 	HIPCHK(mark());
 	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, f0, n, 0, d_chunks, ctx->d_rs_ok, 0);
 	HIPCHK(mark());
@@ -1942,6 +2161,14 @@ int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_byte
 			for (size_t k = 0; k < n; ++k) ((uint8_t*)out)[k] = tmp[k] ? 1 : 0;
 			return (int64_t)bytes;
 		}
+#ifdef FLOOD_PROF
+		case 100: {   // cycle counters of the flood kernel, 6 x u64 per frame: pop, decode, offers, pushes, #pops, #pushes
+			bytes = n * 80;
+			if (out_bytes < bytes) return CIMBAR_HIP_EINVAL;
+			for (size_t k = 0; k < n; ++k) HIPCHK(hipMemcpy((uint8_t*)out + k * 80, ctx->flood.heap + k * HEAP_CAP, 80, hipMemcpyDeviceToHost));
+			return (int64_t)bytes;
+		}
+#endif
 		default: ctx->err = "tap: unknown selector"; return CIMBAR_HIP_EINVAL;
 	}
 	if (out_bytes < bytes) { ctx->err = "tap: buffer too small"; return CIMBAR_HIP_EINVAL; }

@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 synth = framegen.FrameSynth(dev)
 dec = HipDecoder(0)
 st = torch.cuda.current_stream().cuda_stream
-for n in (16, 64, 256):
+for n in (1, 16, 256, 1024):
     payload = framegen.synth_payload(n, seed=7, device=dev)
     frames = torch.roll(synth.frames_from_payload(payload), shifts=(2, 1), dims=(1, 2)).contiguous()
     chunks = torch.zeros((n, 7500), dtype=torch.uint8, device=dev)
