@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "cimbar_hip.hip")
 OUT = os.path.join(HERE, "libcimbar_hip.so")
+OUT_SPILLTEST = os.path.join(HERE, "libcimbar_hip_spilltest.so")   # same code, tiny LDS heap: the flood kernel's spill path under test
 HEADER = os.path.join(os.path.dirname(HERE), "include", "cimbar_hip.h")
 
 
@@ -22,25 +23,31 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the cimbar HIP library cannot be built (there is no CPU fallback)")
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def needs_build(out=OUT):
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     return any(os.path.getmtime(p) > t for p in (SRC, HEADER))
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, out=OUT, defines=()):
     """Compile csrc/cimbar_hip.hip for gfx950 into libcimbar_hip.so. Returns the .so path."""
-    if not force and not needs_build():
-        return OUT
+    if not force and not needs_build(out):
+        return out
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", OUT + ".tmp", SRC]
+           "-Wall", "-Wno-unused-function", *[f"-D{d}" for d in defines], "-o", out + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_spilltest(force=False, verbose=False):
+    """The test-only variant whose flood heap keeps 1024 slots in LDS (everything deeper goes through the spill path)."""
+    return build_hip(force, verbose, OUT_SPILLTEST, ("CIMBAR_HEAP_LDS=1024",))
 
 
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_spilltest(force="--force" in sys.argv, verbose=True))

@@ -591,8 +591,12 @@ __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ pl
 // any): their current instruction lives in s_seed[]. s_state[cell] (u16) = best offered priority + 1, 0x7FFF (no offer yet), or, once
 // visited, 0x8000 | symbol | dx+8 << 4 | dy+8 << 9 -- the results stay in LDS until the frame is done, so the only global
 // accesses inside the loop are the two prefetches.
-constexpr int HEAP_LDS = 10240;  // heap slots held in LDS (40 KiB; a clean shifted frame peaks near 9 200 live entries); deeper slots
-                                 // spill to the global scratch under the same indices
+#ifndef CIMBAR_HEAP_LDS
+#define CIMBAR_HEAP_LDS 10240
+#endif
+constexpr int HEAP_LDS = CIMBAR_HEAP_LDS;  // heap slots held in LDS (40 KiB; a clean shifted frame peaks near 9 200 live entries); deeper slots
+                                 // spill to the global scratch under the same indices (tests build a second library with
+                                 // CIMBAR_HEAP_LDS=1024 so that the spill path runs on ordinary frames)
 struct FloodScratch {
 	uint32_t* heap;      // [F][HEAP_CAP], only indices >= HEAP_LDS are ever touched
 };

@@ -82,8 +82,8 @@ _ERR = {-1: "EINVAL", -2: "EDIM", -3: "ENODEVICE", -4: "EHIP", -5: "ENOMEM"}
 class HipDecoder:
     """One decode context on one GPU (== one reference `Decoder` + its thread_local colour-correction state)."""
 
-    def __init__(self, device=0, mode=68):
-        self._lib = load_library()
+    def __init__(self, device=0, mode=68, lib_path=None):
+        self._lib = load_library(lib_path)   # lib_path: another build of the same ABI (tests: the spill-path variant)
         self._ctx = ctypes.c_void_p()
         rc = self._lib.cimbar_hip_create(int(device), int(mode), ctypes.byref(self._ctx))
         if rc != 0:
