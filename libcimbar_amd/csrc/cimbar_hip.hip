@@ -62,6 +62,9 @@ __constant__ uint8_t c_gf_log[256];
 struct Tables {
 	ushort2* cell_xy;        // [NCELLS] top-left pixel of each cell (CellPositions.cpp:5-51)
 	uint16_t* stream_cell;   // [NCELLS] stream index -> linear cell index (Interleave.h:8-24)
+	uint16_t* cell_grid;     // [NCELLS] grid slot (row * 112 + col) of each cell: where K1 left its 6x6 colour mean
+	uint16_t* ccm_grid;      // [96] grid slot (row * 112 + col) of the cells whose colour the fountain header predicts: colour-stream
+	                         // cells 3100*c + t, t < 24 (CimbReader.cpp:188-227)
 	int16_t* cand;           // [NCELLS][12] the cells FloodDecodePositions::update may offer to, in its order: right, left, bottom,
 	                         // top (AdjacentCellFinder.cpp:16-105), then the 4 horizontal and 4 vertical "horizon" cells
 	                         // (FloodDecodePositions.cpp:93-129); -1 = none
@@ -506,11 +509,16 @@ __device__ __forceinline__ int cell_index(int row, int col)
 // into a few lanes instead of stalling every wave.
 constexpr int K2_BLOCK_ROWS = 16, K2_CELLS = K2_BLOCK_ROWS * DIM;   // 1792 cells per workgroup
 __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ plane, Tables tb, uint8_t* __restrict__ symbols,
-                                                 uint8_t* __restrict__ dist, uint32_t* __restrict__ flood_flag, int f0)
+                                                 uint32_t* __restrict__ flood_flag, int f0)
 {
 	__shared__ uint32_t s_rows[(K2_BLOCK_ROWS * PITCH + 1) * 32];
 	__shared__ uint16_t s_queue[K2_CELLS];
 	__shared__ int s_qn;
+	// the exact-match tables next to the data: per-lane lookups in __constant__ memory are two dependent vector loads per cell
+	__shared__ uint64_t s_tile[16];
+	__shared__ uint8_t s_slot[32];
+	if (threadIdx.x < 16) s_tile[threadIdx.x] = c_tile[threadIdx.x];
+	if (threadIdx.x < 32) s_slot[threadIdx.x] = c_tile_slot[threadIdx.x];
 	const int f = f0 + blockIdx.y;
 	const int brow0 = blockIdx.x * K2_BLOCK_ROWS;
 	const uint32_t* pl = plane + (size_t)f * PLANE_WORDS + (size_t)(OFFSET + brow0 * PITCH - 1) * 32;   // first bit row needed: y0 - 1
@@ -535,10 +543,10 @@ __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ pl
 			uint64_t w = ((uint64_t)r[(k + 4) * 32 + j] << 32) | r[(k + 4) * 32 + j1];
 			lo = (lo << 8) | ((uint32_t)(w >> sh) & 0xFFu);
 		}
-		const uint32_t sym = exact_tile(((uint64_t)hi << 32) | lo);
-		if (sym < 16) {
-			symbols[(size_t)f * NCELLS + i] = (uint8_t)sym;
-			if (dist) dist[(size_t)f * NCELLS + i] = 0;
+		const uint32_t slot = s_slot[((lo ^ hi) * 0x61b91u) >> 27];
+		const uint64_t cand_tile = s_tile[slot & 15u];
+		if (slot < 16 && cand_tile == (((uint64_t)hi << 32) | lo)) {
+			symbols[(size_t)f * NCELLS + i] = (uint8_t)slot;
 		} else {
 			s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)lc;
 		}
@@ -556,7 +564,6 @@ __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ pl
 		const uint32_t centre = best_tile(window_hash(rows, 4));
 		const uint32_t dc = centre >> 4;
 		symbols[(size_t)f * NCELLS + i] = (uint8_t)(centre & 15u);
-		if (dist) dist[(size_t)f * NCELLS + i] = (uint8_t)dc;
 		if (dc != 0) {
 			uint32_t other = 0xFFFFu;
 			const int side[4] = {5, 7, 3, 1};
@@ -1265,21 +1272,13 @@ __device__ __forceinline__ void mean6x6(const uint8_t* __restrict__ frame, int x
 // ---- float arithmetic that must match the CPU restatement operation for operation: no contraction, IEEE div/sqrt
 #pragma clang fp contract(off)
 
-// CimbReader.cpp:55-86 calculateWhite (dark): three 4x4 anchor-centre means (cv::mean -> double), max, floor (1,1,1)
-__device__ void calculate_white(const uint8_t* __restrict__ frame, float white[3])
+// CimbReader.cpp:55-86 calculateWhite (dark): three 4x4 anchor-centre means (cv::mean -> double), max, floor (1,1,1).
+// sums[a*3+c] = the integer sum of channel c over anchor a's 16 pixels; sum/16 is exact in double and in float.
+__device__ __forceinline__ void white_from_sums(const uint32_t* sums, float white[3])
 {
-	const int tl = ANCHOR - 2, far = IMG - ANCHOR - 2;
-	const int ax[3] = {tl, tl, far}, ay[3] = {tl, far, tl};
 	white[0] = white[1] = white[2] = 1.0f;
-	for (int a = 0; a < 3; ++a) {
-		double sm[3] = {0, 0, 0};
-		for (int i = 0; i < 4; ++i)
-			for (int j = 0; j < 4; ++j) {
-				const uint8_t* p = frame + ((size_t)(ay[a] + i) * IMG + (ax[a] + j)) * 3;
-				sm[0] += p[0]; sm[1] += p[1]; sm[2] += p[2];
-			}
-		for (int c = 0; c < 3; ++c) { float v = (float)(sm[c] / 16.0); if (v > white[c]) white[c] = v; }
-	}
+	for (int a = 0; a < 3; ++a)
+		for (int c = 0; c < 3; ++c) { float v = (float)((double)sums[a * 3 + c] / 16.0); if (v > white[c]) white[c] = v; }
 }
 
 // [assumed-OpenCV] lapack.cpp JacobiSVDImpl_<float>, n = 3 rows of length m = R (<= 5); same operation order as
@@ -1438,13 +1437,17 @@ __device__ __forceinline__ uint32_t best_color(float r, float g, float b, const 
 	float adjust = __fdiv_rn(255.0f, mx - mn);
 	int c0 = (int)fix_single_color(r, adjust, mn), c1 = (int)fix_single_color(g, adjust, mn), c2 = (int)fix_single_color(b, adjust, mn);
 	int rel0 = c0 - c1, rel1 = c1 - c2, rel2 = c2 - c0;
-	uint32_t best_fit = 0, best_distance = 1000000u;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		int q0 = c_palette[i][0] - c_palette[i][1], q1 = c_palette[i][1] - c_palette[i][2], q2 = c_palette[i][2] - c_palette[i][0];
-		uint32_t d = (uint32_t)((rel0 - q0) * (rel0 - q0) + (rel1 - q1) * (rel1 - q1) + (rel2 - q2) * (rel2 - q2));
-		if (d < best_distance) { best_fit = (uint32_t)i; best_distance = d; }
-	}
+	// CimbDecoder.cpp:186-198: the palette entry i minimising |rel - q_i|^2, q_i = (p0-p1, p1-p2, p2-p0), first minimum wins.
+	// For the mode-B palette every q_i is a signed permutation of (255, -255, 0): |q_i|^2 is the same for all four, so the
+	// minimum of the distance is the maximum of rel . q_i (first maximum wins) -- four differences instead of four
+	// three-term squared distances:  q_0 = (-255, 255, 0), q_1 = (-255, 0, 255), q_2 = (0, 255, -255), q_3 = (255, -255, 0)
+	// (the palette of c_palette -- {0,255,0},{0,255,255},{255,255,0},{255,0,255} -- is baked into these four differences)
+	const int t0 = rel1 - rel0, t1 = rel2 - rel0, t2 = rel1 - rel2, t3 = rel0 - rel1;
+	uint32_t best_fit = 0;
+	int bt = t0;
+	if (t1 > bt) { best_fit = 1; bt = t1; }
+	if (t2 > bt) { best_fit = 2; bt = t2; }
+	if (t3 > bt) { best_fit = 3; bt = t3; }
 	return best_fit;
 }
 #pragma clang fp contract(fast)
@@ -1463,11 +1466,31 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 	__shared__ int s_have_hdr;
 	__shared__ uint32_t s_cnt[4], s_r[4], s_g[4], s_b[4], s_first[4];
 
-	// one load per lane instead of 40 + 6 dependent ones on lane 0: RS flags -> ballot, chunk headers -> LDS
+	// Everything this kernel reads from global memory is requested here, before anything waits: the kernel is one wavefront
+	// per frame running a long serial chain (aligner, Jacobi SVD), so every dependent round trip to HBM shows in its latency.
+	//   RS flags -> ballot, chunk headers -> LDS, the 96 header-predicted cells' means, the 48 anchor pixels of calculateWhite
 	__shared__ uint8_t s_chunk_hdr[8 * CHUNK];   // only bytes [j*625, j*625+6) are filled / read (aligner_block's indexing)
-	const unsigned long long ok_bits = __ballot(lane < SYM_BLOCKS && rs_ok[(size_t)f * ALL_BLOCKS + (lane < SYM_BLOCKS ? lane : 0)] != 0);
-	if (lane < 48) s_chunk_hdr[(lane / 6) * CHUNK + lane % 6] = fc[(size_t)(lane / 6) * CHUNK + lane % 6];
+	__shared__ uint32_t s_white[9];               // [anchor][channel] sums over the 4x4 anchor centres
+	const uint8_t okb = lane < SYM_BLOCKS ? rs_ok[(size_t)f * ALL_BLOCKS + lane] : (uint8_t)0;
+	const uint8_t hdrb = lane < 48 ? fc[(size_t)(lane / 6) * CHUNK + lane % 6] : (uint8_t)0;
+	const bool need_cells = color_correction == 2, need_white = color_correction == 1 || color_correction == 2;
+	uint32_t mv0 = 0, mv1 = 0, px[3] = {0, 0, 0};
+	if (need_cells) {
+		mv0 = cellmean[(size_t)f * GRID_CELLS + tb.ccm_grid[lane]];
+		if (lane < 32) mv1 = cellmean[(size_t)f * GRID_CELLS + tb.ccm_grid[64 + lane]];
+	}
+	if (need_white && lane < 48) {
+		// CimbReader.cpp:55-86 calculateWhite (dark): three 4x4 anchor-centre blocks; lane = anchor * 16 + row * 4 + col
+		const int tl = ANCHOR - 2, far = IMG - ANCHOR - 2;
+		const int a = lane >> 4, ax = a == 2 ? far : tl, ay = a == 1 ? far : tl;
+		const uint8_t* p = frame + ((size_t)(ay + ((lane >> 2) & 3)) * IMG + (ax + (lane & 3))) * 3;
+		px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
+	}
+	if (lane < 9) s_white[lane] = 0;
+	const unsigned long long ok_bits = __ballot(okb != 0);
+	if (lane < 48) s_chunk_hdr[(lane / 6) * CHUNK + lane % 6] = hdrb;
 	__syncthreads();
+	if (need_white && lane < 48) { atomicAdd(&s_white[(lane >> 4) * 3], px[0]); atomicAdd(&s_white[(lane >> 4) * 3 + 1], px[1]); atomicAdd(&s_white[(lane >> 4) * 3 + 2], px[2]); }
 	if (lane == 0) {
 		FrameState st = {0, 0, 0, 0};
 		uint8_t hdr[6] = {0, 0, 0, 0, 0, 0};
@@ -1487,7 +1510,7 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 	if (color_correction == 1) {
 		if (lane == 0) {
 			float white[3], m[9];
-			calculate_white(frame, white);
+			white_from_sums(s_white, white);
 			von_kries_ccm(white, m);
 			for (int k = 0; k < 9; ++k) out[k] = m[k];
 			out[9] = 1.0f;
@@ -1499,19 +1522,16 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 		return;
 	}
 
-	// 96 known-colour cells: colour-stream cells 3100*c + t, t < 24; expected colour = bits [2t, 2t+2) of header c
+	// 96 known-colour cells: colour-stream cells 3100*c + t, t < 24; expected colour = bits [2t, 2t+2) of header c. Their means
+	// (undrifted grid position + 1, 6x6, CimbReader.cpp:216-217: exactly what K1 left in cellmean) were fetched at the top.
 	for (int q = lane; q < 96; q += 64) {
 		const int c = q / 24, t = q % 24;
 		const uint32_t expected = ((uint32_t)s_hdr[c][t >> 2] >> (6 - 2 * (t & 3))) & 3u;
-		const int cell = tb.stream_cell[3100 * c + t];
-		ushort2 xy = tb.cell_xy[cell];
-		// undrifted grid position + 1, 6x6 (CimbReader.cpp:216-217): exactly what K1 left in cellmean
-		const uint32_t mv = cellmean[(size_t)f * GRID_CELLS + (((int)xy.y - OFFSET) / PITCH) * DIM + ((int)xy.x - OFFSET) / PITCH];
-		const uint32_t col[3] = {mv & 0xFFu, (mv >> 8) & 0xFFu, (mv >> 16) & 0xFFu};
+		const uint32_t mv = q < 64 ? mv0 : mv1;
 		atomicAdd(&s_cnt[expected], 1u);
-		atomicAdd(&s_r[expected], col[0]);
-		atomicAdd(&s_g[expected], col[1]);
-		atomicAdd(&s_b[expected], col[2]);
+		atomicAdd(&s_r[expected], mv & 0xFFu);
+		atomicAdd(&s_g[expected], (mv >> 8) & 0xFFu);
+		atomicAdd(&s_b[expected], (mv >> 16) & 0xFFu);
 		atomicMin(&s_first[expected], (uint32_t)q);
 	}
 	__syncthreads();
@@ -1535,7 +1555,7 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 		}
 		if (rows < 4) { out[9] = 0.0f; return; }
 		float white[3], m[9];
-		calculate_white(frame, white);
+		white_from_sums(s_white, white);
 		actual[rows * 3] = white[0]; actual[rows * 3 + 1] = white[1]; actual[rows * 3 + 2] = white[2];
 		desired[rows * 3] = desired[rows * 3 + 1] = desired[rows * 3 + 2] = 255.0f;
 		++rows;
@@ -1573,10 +1593,7 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 		for (int k = 0; k < K5_CELLS; ++k) {
 			const int i = (blockIdx.x * K5_CELLS + k) * 256 + threadIdx.x;
 			mv[k] = 0;
-			if (i < NCELLS) {
-				ushort2 xy = tb.cell_xy[i];
-				mv[k] = cellmean[(size_t)f * GRID_CELLS + (((int)xy.y - OFFSET) / PITCH) * DIM + ((int)xy.x - OFFSET) / PITCH];
-			}
+			if (i < NCELLS) mv[k] = cellmean[(size_t)f * GRID_CELLS + tb.cell_grid[i]];
 		}
 	}
 #pragma unroll
@@ -1741,7 +1758,6 @@ struct cimbar_hip_ctx {
 	uint32_t* d_cellmean = nullptr;
 	uint8_t* d_symbols = nullptr;
 	uint8_t* d_colors = nullptr;
-	uint8_t* d_dist = nullptr;
 	int8_t* d_drift = nullptr;
 	uint32_t* d_flood = nullptr;
 	uint8_t* d_rs_ok = nullptr;
@@ -1875,6 +1891,17 @@ int build_tables(cimbar_hip_ctx* ctx)
 	}
 	HIPCHK(hipMalloc(&ctx->tb.cell_xy, sizeof(ushort2) * NCELLS));
 	HIPCHK(hipMalloc(&ctx->tb.stream_cell, sizeof(uint16_t) * NCELLS));
+	std::vector<uint16_t> cell_grid(NCELLS);
+	for (int i = 0; i < NCELLS; ++i) cell_grid[i] = (uint16_t)((((int)xy[i].y - OFFSET) / PITCH) * DIM + ((int)xy[i].x - OFFSET) / PITCH);
+	HIPCHK(hipMalloc(&ctx->tb.cell_grid, sizeof(uint16_t) * NCELLS));
+	HIPCHK(hipMemcpy(ctx->tb.cell_grid, cell_grid.data(), sizeof(uint16_t) * NCELLS, hipMemcpyHostToDevice));
+	std::vector<uint16_t> ccm_grid(96);
+	for (int q = 0; q < 96; ++q) {
+		const int cell = sc[3100 * (q / 24) + q % 24];
+		ccm_grid[q] = (uint16_t)((((int)xy[cell].y - OFFSET) / PITCH) * DIM + ((int)xy[cell].x - OFFSET) / PITCH);
+	}
+	HIPCHK(hipMalloc(&ctx->tb.ccm_grid, sizeof(uint16_t) * 96));
+	HIPCHK(hipMemcpy(ctx->tb.ccm_grid, ccm_grid.data(), sizeof(uint16_t) * 96, hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc(&ctx->tb.cand, sizeof(int16_t) * NCELLS * 12));
 	HIPCHK(hipMemcpy(ctx->tb.cell_xy, xy.data(), sizeof(ushort2) * NCELLS, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(ctx->tb.stream_cell, sc.data(), sizeof(uint16_t) * NCELLS, hipMemcpyHostToDevice));
@@ -1911,7 +1938,6 @@ int ensure_capacity(cimbar_hip_ctx* ctx, int n)
 	HIPCHK(regrow(ctx->d_cellmean, N * GRID_CELLS));
 	HIPCHK(regrow(ctx->d_symbols, N * NCELLS));
 	HIPCHK(regrow(ctx->d_colors, N * NCELLS));
-	HIPCHK(regrow(ctx->d_dist, N * NCELLS));
 	HIPCHK(regrow(ctx->d_drift, N * NCELLS * 2));
 	HIPCHK(regrow(ctx->d_flood, N));
 	HIPCHK(regrow(ctx->d_rs_ok, N * ALL_BLOCKS));
@@ -1930,8 +1956,8 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	auto fr = [](void* p) { if (p) (void)hipFree(p); };
-	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.cand);
-	fr(ctx->d_template); fr(ctx->d_gen_log); fr(ctx->d_payload); fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_dist); fr(ctx->d_drift); fr(ctx->d_flood);
+	fr(ctx->tb.cell_xy); fr(ctx->tb.stream_cell); fr(ctx->tb.cand); fr(ctx->tb.ccm_grid); fr(ctx->tb.cell_grid);
+	fr(ctx->d_template); fr(ctx->d_gen_log); fr(ctx->d_payload); fr(ctx->d_rgb); fr(ctx->d_plane); fr(ctx->d_cellmean); fr(ctx->d_symbols); fr(ctx->d_colors); fr(ctx->d_drift); fr(ctx->d_flood);
 	fr(ctx->d_rs_ok); fr(ctx->d_states); fr(ctx->d_ccm_frames); fr(ctx->d_ccm_used); fr(ctx->d_carry); fr(ctx->d_chunks);
 	fr(ctx->d_masks); fr(ctx->flood.heap);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1955,7 +1981,7 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, f0);
 	}
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_dist, ctx->d_flood, f0);
+	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_flood, f0);
 	HIPCHK(mark());
 	hipLaunchKernelGGL(k_flood, dim3(n < FLOOD_GRID ? n : FLOOD_GRID), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
 	                   ctx->d_drift, f0, n);
