@@ -1617,11 +1617,11 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
                                                   uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
                                                   const float* __restrict__ ccm_used,
-                                                  float* __restrict__ carry, int f0)
+                                                  float* __restrict__ carry, int f0, int write_carry)
 {
 	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	// the matrix carried into the next call = the one in force for the batch's last frame (CimbDecoder.cpp:69-85)
-	if (blockIdx.x == gridDim.x - 1 && lane < 10) carry[lane] = ccm_used[(size_t)f * 10 + lane];
+	if (write_carry && blockIdx.x == gridDim.x - 1 && lane < 10) carry[lane] = ccm_used[(size_t)f * 10 + lane];
 	__shared__ uint32_t s_mask;
 	const unsigned long long ok_bits = __ballot(lane < COL_BLOCKS && rs_ok[(size_t)f * ALL_BLOCKS + SYM_BLOCKS + (lane < COL_BLOCKS ? lane : 0)] != 0);
 	if (lane == 0) {
@@ -1747,6 +1747,9 @@ __global__ void k_plane_bytes(const uint32_t* __restrict__ plane, uint8_t* __res
 struct cimbar_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr;            // second half of a batch's tail kernels (see enqueue)
+	hipEvent_t ev_k1 = nullptr, ev_join = nullptr, ev_mid[8] = {};
+	int tail_split = 1, tail_parts = 2;
 	std::string err;
 	Tables tb{};
 	// batch scratch (grown on demand)
@@ -1962,6 +1965,9 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	fr(ctx->d_masks); fr(ctx->flood.heap);
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+	for (hipEvent_t e : {ctx->ev_k1, ctx->ev_join}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : ctx->ev_mid) if (e) (void)hipEventDestroy(e);
 	delete ctx;
 }
 
@@ -1981,21 +1987,59 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		else hipLaunchKernelGGL((k_threshold<2, false>), g, dim3(256), 0, st, d_rgb, ctx->d_plane, ctx->d_cellmean, ctx->d_flood, f0);
 	}
 	HIPCHK(mark());
-	hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, n), dim3(256), 0, st, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_flood, f0);
-	HIPCHK(mark());
-	hipLaunchKernelGGL(k_flood, dim3(n < FLOOD_GRID ? n : FLOOD_GRID), dim3(64), 0, st, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
-	                   ctx->d_drift, f0, n);
-	HIPCHK(mark());
-	hipLaunchKernelGGL((k_rs<4>), dim3((n * SYM_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_symbols, ctx->tb, f0, n, 0, d_chunks, ctx->d_rs_ok, 0);
-	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_mid, dim3(n), dim3(64), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, f0);
-	HIPCHK(mark());
-	hipLaunchKernelGGL(k_colors, dim3((NCELLS + 256 * K5_CELLS - 1) / (256 * K5_CELLS), n), dim3(256), 0, st, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames, ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used, f0);
-	HIPCHK(mark());
-	hipLaunchKernelGGL((k_rs<2>), dim3((n * COL_BLOCKS + 3) / 4), dim3(256), 0, st, ctx->d_colors, ctx->tb, f0, n, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
-	HIPCHK(mark());
-	hipLaunchKernelGGL(k_frame_end, dim3(n), dim3(64), 0, st, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_ccm_used, ctx->d_carry, f0);
-	HIPCHK(mark());
+	// Everything after K1 is a chain of small kernels per frame (symbols -> flood -> RS -> header/CCM -> colours -> RS -> masks), some of
+	// them latency-bound (k_frame_mid is one serial wavefront per frame). For a large batch the chain runs as two half-batches on two
+	// streams, so one half's serial phases and launch gaps are covered by the other half's kernels. The only cross-half dependency
+	// is the colour-correction carry: a frame with no matrix of its own takes the newest one of the frames before it, so the second
+	// half's colour pass waits for the first half's k_frame_mid. Stage timing uses the single-stream order.
+	const bool split = !tm && ctx->tail_split && n >= 64 * ctx->tail_parts;
+	auto tail = [&](hipStream_t s, int fa, int m, int part) -> hipError_t {
+		// part 0: up to k_frame_mid, part 1: the rest
+		if (part == 0) {
+			hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, m), dim3(256), 0, s, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_flood, fa);
+			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
+			hipLaunchKernelGGL(k_flood, dim3(m < FLOOD_GRID ? m : FLOOD_GRID), dim3(64), 0, s, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
+			                   ctx->d_drift, fa, m);
+			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
+			hipLaunchKernelGGL((k_rs<4>), dim3((m * SYM_BLOCKS + 3) / 4), dim3(256), 0, s, ctx->d_symbols, ctx->tb, fa, m, 0, d_chunks, ctx->d_rs_ok, 0);
+			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
+			hipLaunchKernelGGL(k_frame_mid, dim3(m), dim3(64), 0, s, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, fa);
+			return s == st ? mark() : hipSuccess;
+		}
+		hipLaunchKernelGGL(k_colors, dim3((NCELLS + 256 * K5_CELLS - 1) / (256 * K5_CELLS), m), dim3(256), 0, s, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames,
+		                   ctx->d_carry, ctx->d_flood, ctx->d_drift, ctx->d_colors, ctx->d_ccm_used, fa);
+		if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
+		hipLaunchKernelGGL((k_rs<2>), dim3((m * COL_BLOCKS + 3) / 4), dim3(256), 0, s, ctx->d_colors, ctx->tb, fa, m, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
+		if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
+		hipLaunchKernelGGL(k_frame_end, dim3(m), dim3(64), 0, s, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_ccm_used, ctx->d_carry, fa,
+		                   fa + m == n ? 1 : 0);
+		return s == st ? mark() : hipSuccess;
+	};
+	if (!split) {
+		HIPCHK(tail(st, f0, n, 0));
+		HIPCHK(tail(st, f0, n, 1));
+	} else {
+		// parts alternate between the caller's stream and stream2; pairs are issued together so that both streams always have work
+		const int P = ctx->tail_parts;
+		hipStream_t sb = ctx->stream2;
+		auto lo = [&](int p) { return (int)((long long)n * p / P); };
+		HIPCHK(hipEventRecord(ctx->ev_k1, st));
+		HIPCHK(hipStreamWaitEvent(sb, ctx->ev_k1, 0));
+		for (int p = 0; p < P; p += 2) {
+			for (int q = p; q < p + 2; ++q) {
+				hipStream_t sq = (q & 1) ? sb : st;
+				HIPCHK(tail(sq, f0 + lo(q), lo(q + 1) - lo(q), 0));
+				HIPCHK(hipEventRecord(ctx->ev_mid[q], sq));
+			}
+			for (int q = p; q < p + 2; ++q) {
+				hipStream_t sq = (q & 1) ? sb : st;
+				if (q > 0) HIPCHK(hipStreamWaitEvent(sq, ctx->ev_mid[q - 1], 0));   // every k_frame_mid of the frames before this part is done
+				HIPCHK(tail(sq, f0 + lo(q), lo(q + 1) - lo(q), 1));
+			}
+		}
+		HIPCHK(hipEventRecord(ctx->ev_join, sb));
+		HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+	}
 	HIPCHK(hipGetLastError());
 	ctx->last_n = n;
 	return 0;
@@ -2023,6 +2067,12 @@ int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out)
 	ctx->device = device;
 	auto fail = [&](int code) { destroy_ctx(ctx); return code; };
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	for (hipEvent_t* e : {&ctx->ev_k1, &ctx->ev_join})
+		if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	for (hipEvent_t& e : ctx->ev_mid) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (const char* v = std::getenv("CIMBAR_HIP_TAIL_SPLIT")) ctx->tail_split = std::atoi(v);
+	if (const char* v = std::getenv("CIMBAR_HIP_TAIL_PARTS")) { int k = std::atoi(v); if (k >= 2 && k <= 8 && k % 2 == 0) ctx->tail_parts = k; }
 	for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	if (hipMalloc(&ctx->d_carry, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_ENOMEM);
 	if (hipMemset(ctx->d_carry, 0, sizeof(float) * 10) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
