@@ -75,6 +75,17 @@ int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
 int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
                                 int color_correction, uint8_t* chunks, uint32_t* masks, int out_mem, void* hip_stream);
 
+/* Decoder::decode(img, ostream, should_preprocess, color_correction) (src/lib/encoder/Decoder.h:163-169) -- the `./cimbar --no-fountain`
+ * path (cimbar.cpp:270-272) -- for n frames: no aligned_stream, every 125-byte Reed-Solomon output is written where it falls and a
+ * block libcorrect could not decode is written as 125 zero bytes (reed_solomon_stream.h:62-74,96-107).
+ *   bytes    : n * 7500 bytes (60 blocks of 125 per frame: 40 from the symbol bits, then 20 from the colour bits)
+ *   block_ok : n * 60 bytes, 1 = the block decoded; may be NULL. Same memory kind as `bytes`.
+ * No fountain header reaches the reader on this path, so color_correction == 2 keeps whatever matrix the context carries
+ * (CimbReader.cpp:169-180). Host outputs: synchronises and returns n * 7500 (what the stream's tellp() advanced by, Decoder.h:116-117);
+ * device outputs: enqueues and returns 0. Buffers, stream and errors as for cimbar_hip_decode_batch. */
+int64_t cimbar_hip_decode_plain_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
+                                      int color_correction, uint8_t* bytes, uint8_t* block_ok, int out_mem, void* hip_stream);
+
 /* Clears the carried colour-correction state (what a fresh thread starts with in the reference). */
 int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx);
 /* Current carried CCM, row-major 3x3; returns 1 if active, 0 if not (CimbDecoder::get_ccm, CimbDecoder.cpp:76-80). */

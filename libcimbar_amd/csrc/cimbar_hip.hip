@@ -1457,7 +1457,8 @@ __device__ __forceinline__ uint32_t best_color(float r, float g, float b, const 
 // ccm_out[f] = {9 floats, valid}; valid == 0 means "keep whatever the thread had" (resolved in k_colors).
 __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rgb, const uint32_t* __restrict__ cellmean, Tables tb,
                                                   const uint8_t* __restrict__ chunks, const uint8_t* __restrict__ rs_ok,
-                                                  int color_correction, FrameState* __restrict__ states, float* __restrict__ ccm_out, int f0)
+                                                  int color_correction, FrameState* __restrict__ states, float* __restrict__ ccm_out, int f0,
+                                                  int plain)
 {
 	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	const uint8_t* frame = rgb + (size_t)f * FRAME_RGB;
@@ -1497,7 +1498,8 @@ __global__ __launch_bounds__(64) void k_frame_mid(const uint8_t* __restrict__ rg
 		unsigned radio = 0;
 		for (int b = 0; b < SYM_BLOCKS; ++b) aligner_block(st, b, (int)((ok_bits >> b) & 1ull), s_chunk_hdr, true, hdr, radio);
 		states[f] = st;
-		s_have_hdr = md_id(hdr) != 0;
+		// Decoder::decode into a plain stream has no aligned_stream, so no fountain header ever reaches the reader (Decoder.h:163-169)
+		s_have_hdr = !plain && md_id(hdr) != 0;
 		for (int c = 0; c < 4; ++c) {
 			for (int k = 0; k < 6; ++k) s_hdr[c][k] = hdr[k];
 			md_increment(hdr, radio);
@@ -1617,11 +1619,21 @@ __global__ __launch_bounds__(256) void k_colors(const uint8_t* __restrict__ rgb,
 __global__ __launch_bounds__(64) void k_frame_end(const uint8_t* __restrict__ rs_ok, FrameState* __restrict__ states,
                                                   uint8_t* __restrict__ chunks, uint32_t* __restrict__ masks,
                                                   const float* __restrict__ ccm_used,
-                                                  float* __restrict__ carry, int f0, int write_carry)
+                                                  float* __restrict__ carry, int f0, int write_carry, int plain)
 {
 	const int f = f0 + blockIdx.x, lane = threadIdx.x;
 	// the matrix carried into the next call = the one in force for the batch's last frame (CimbDecoder.cpp:69-85)
 	if (write_carry && blockIdx.x == gridDim.x - 1 && lane < 10) carry[lane] = ccm_used[(size_t)f * 10 + lane];
+	if (plain) {
+		// Decoder::decode into a plain stream: every RS output is written where it falls, a failed block as 125 zero bytes
+		// (reed_solomon_stream.h:62-74,96-107). masks[f] is not meaningful here; the per-block flags are in rs_ok.
+		uint8_t* fb = chunks + (size_t)f * FRAME_BYTES;
+		for (int b = 0; b < ALL_BLOCKS; ++b)
+			if (!rs_ok[(size_t)f * ALL_BLOCKS + b])
+				for (int k = lane; k < RS_DATA; k += 64) fb[(size_t)b * RS_DATA + k] = 0;
+		if (lane == 0) masks[f] = 0;
+		return;
+	}
 	__shared__ uint32_t s_mask;
 	const unsigned long long ok_bits = __ballot(lane < COL_BLOCKS && rs_ok[(size_t)f * ALL_BLOCKS + SYM_BLOCKS + (lane < COL_BLOCKS ? lane : 0)] != 0);
 	if (lane == 0) {
@@ -1972,7 +1984,7 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 }
 
 // enqueue the whole pipeline for n device-resident frames on stream `st`
-int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks)
+int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks, int plain = 0)
 {
 	const bool tm = ctx->timing;
 	int evi = 0;
@@ -2003,7 +2015,7 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
 			hipLaunchKernelGGL((k_rs<4>), dim3((m * SYM_BLOCKS + 3) / 4), dim3(256), 0, s, ctx->d_symbols, ctx->tb, fa, m, 0, d_chunks, ctx->d_rs_ok, 0);
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
-			hipLaunchKernelGGL(k_frame_mid, dim3(m), dim3(64), 0, s, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, fa);
+			hipLaunchKernelGGL(k_frame_mid, dim3(m), dim3(64), 0, s, d_rgb, ctx->d_cellmean, ctx->tb, d_chunks, ctx->d_rs_ok, cc, ctx->d_states, ctx->d_ccm_frames, fa, plain);
 			return s == st ? mark() : hipSuccess;
 		}
 		hipLaunchKernelGGL(k_colors, dim3((NCELLS + 256 * K5_CELLS - 1) / (256 * K5_CELLS), m), dim3(256), 0, s, d_rgb, ctx->d_cellmean, ctx->tb, ctx->d_ccm_frames,
@@ -2012,7 +2024,7 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		hipLaunchKernelGGL((k_rs<2>), dim3((m * COL_BLOCKS + 3) / 4), dim3(256), 0, s, ctx->d_colors, ctx->tb, fa, m, 8, d_chunks, ctx->d_rs_ok, SYM_BLOCKS);
 		if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
 		hipLaunchKernelGGL(k_frame_end, dim3(m), dim3(64), 0, s, ctx->d_rs_ok, ctx->d_states, d_chunks, d_masks, ctx->d_ccm_used, ctx->d_carry, fa,
-		                   fa + m == n ? 1 : 0);
+		                   fa + m == n ? 1 : 0, plain);
 		return s == st ? mark() : hipSuccess;
 	};
 	if (!split) {
@@ -2143,6 +2155,36 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 	// aligned_stream::tellp() summed over the batch: 625 bytes per delivered chunk (aligned_stream.h:29-32)
 	for (int f = 0; f < n; ++f) total += (unsigned long long)CHUNK * (unsigned)__builtin_popcount(masks[f] & 0xFFFu);
 	return (int64_t)total;
+}
+
+int64_t cimbar_hip_decode_plain_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
+                                      int color_correction, uint8_t* bytes, uint8_t* block_ok, int out_mem, void* hip_stream)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (!rgb || !bytes || n <= 0) { ctx->err = "decode_plain_batch: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
+	if ((rgb_mem != CIMBAR_HIP_MEM_HOST && rgb_mem != CIMBAR_HIP_MEM_DEVICE) || (out_mem != CIMBAR_HIP_MEM_HOST && out_mem != CIMBAR_HIP_MEM_DEVICE)) {
+		ctx->err = "decode_plain_batch: rgb_mem / out_mem must be CIMBAR_HIP_MEM_HOST or CIMBAR_HIP_MEM_DEVICE";
+		return CIMBAR_HIP_EINVAL;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const bool any_device = rgb_mem == CIMBAR_HIP_MEM_DEVICE || out_mem == CIMBAR_HIP_MEM_DEVICE;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
+	if (int r = ensure_capacity(ctx, n)) return r;
+	const uint8_t* d_rgb = rgb;
+	if (rgb_mem == CIMBAR_HIP_MEM_HOST) {
+		size_t need = (size_t)n * FRAME_RGB;
+		if (need > ctx->d_rgb_cap) { HIPCHK(regrow(ctx->d_rgb, need)); ctx->d_rgb_cap = need; }
+		HIPCHK(hipMemcpyAsync(ctx->d_rgb, rgb, need, hipMemcpyHostToDevice, st));
+		d_rgb = ctx->d_rgb;
+	}
+	uint8_t* d_bytes = out_mem == CIMBAR_HIP_MEM_DEVICE ? bytes : ctx->d_chunks;
+	if (int r = enqueue(ctx, st, d_rgb, n, should_preprocess, color_correction, d_bytes, ctx->d_masks, 1)) return r;
+	if (block_ok)
+		HIPCHK(hipMemcpyAsync(block_ok, ctx->d_rs_ok, (size_t)n * ALL_BLOCKS, out_mem == CIMBAR_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+	if (out_mem == CIMBAR_HIP_MEM_DEVICE) return 0;
+	HIPCHK(hipMemcpyAsync(bytes, d_bytes, (size_t)n * FRAME_BYTES, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	return (int64_t)n * FRAME_BYTES;   // what tellp() of the output stream advanced by: every block is written, good or zeroed
 }
 
 int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,

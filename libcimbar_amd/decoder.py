@@ -23,7 +23,7 @@ TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM 
 EXPORTS = (
     "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
-    "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch",
+    "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
 )
 
 
@@ -57,6 +57,8 @@ def load_library(path=None):
     lib.cimbar_hip_decode_frame.restype = i32
     lib.cimbar_hip_decode_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.cimbar_hip_decode_batch.restype = i64
+    lib.cimbar_hip_decode_plain_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_decode_plain_batch.restype = i64
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -135,6 +137,20 @@ class HipDecoder:
                                                int(color_correction), chunks.ctypes.data, masks.ctypes.data, MEM_HOST, None)
         self._check(rc, "cimbar_hip_decode_batch")
         return int(rc), chunks, masks
+
+    def decode_plain_batch(self, frames, should_preprocess=False, color_correction=2):
+        """Decoder::decode (the --no-fountain path) for frames (n,1024,1024,3) uint8 numpy. Returns (bytes_written,
+        data (n,7500) uint8 with failed RS blocks zeroed, block_ok (n,60) uint8)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        if frames.shape[1:] != (modeb.IMG, modeb.IMG, 3):
+            raise CimbarHipError("decode_plain_batch: frames must be (n,1024,1024,3) uint8")
+        data = np.zeros((n, modeb.FRAME_BYTES), dtype=np.uint8)
+        ok = np.zeros((n, 60), dtype=np.uint8)
+        rc = self._lib.cimbar_hip_decode_plain_batch(self._ctx, frames.ctypes.data, n, MEM_HOST, int(bool(should_preprocess)),
+                                                     int(color_correction), data.ctypes.data, ok.ctypes.data, MEM_HOST, None)
+        self._check(rc, "cimbar_hip_decode_plain_batch")
+        return int(rc), data, ok
 
     # ------------------------------------------------------------------ device-memory entry point (torch tensors as raw memory)
     def decode_batch_device(self, frames_ptr, n, chunks_ptr, masks_ptr, should_preprocess=False, color_correction=2, stream=None):

@@ -77,6 +77,32 @@ public:
 		return (unsigned)res;
 	}
 
+	// Decoder::decode (Decoder.h:163-169), the `--no-fountain` path (cimbar.cpp:270-272): the frame's 60 Reed-Solomon outputs go to
+	// ostream.write back to back, a block that could not be decoded as 125 zero bytes (what reed_solomon_stream does for an
+	// ofstream / stringstream, reed_solomon_stream.h:96-107). Returns ostream.tellp() like the reference (Decoder.h:116-117).
+	template <typename MAT, typename STREAM>
+	unsigned decode(const MAT& img, STREAM& ostream, bool should_preprocess = false, int color_correction = 2)
+	{
+		if (!_ctx) return 0;
+		if ((unsigned)img.cols != (unsigned)CIMBAR_HIP_FRAME_DIM || (unsigned)img.rows != (unsigned)CIMBAR_HIP_FRAME_DIM) { _rc = CIMBAR_HIP_EDIM; return 0; }
+		std::vector<unsigned char> packed;
+		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
+		const size_t step = image_step(img), dense = (size_t)CIMBAR_HIP_FRAME_DIM * 3;
+		if (step != dense) {
+			packed.resize(dense * CIMBAR_HIP_FRAME_DIM);
+			for (int y = 0; y < CIMBAR_HIP_FRAME_DIM; ++y)
+				for (size_t k = 0; k < dense; ++k) packed[(size_t)y * dense + k] = src[(size_t)y * step + k];
+			src = packed.data();
+		}
+		unsigned char bytes[CIMBAR_HIP_FRAME_BYTES];
+		int64_t res = cimbar_hip_decode_plain_batch(_ctx, src, 1, CIMBAR_HIP_MEM_HOST, should_preprocess ? 1 : 0, color_correction, bytes, nullptr,
+		                                            CIMBAR_HIP_MEM_HOST, nullptr);
+		_rc = res < 0 ? (int)res : 0;
+		if (res <= 0) return 0;
+		ostream.write(reinterpret_cast<const char*>(bytes), CIMBAR_HIP_FRAME_BYTES);
+		return (unsigned)ostream.tellp();
+	}
+
 	// n densely packed 1024x1024 RGB8 frames in host memory, decoded on the GPU in one batch; chunks go to the sink in frame
 	// order then chunk order (what a single-threaded reference loop over the frames would have produced). Returns total good bytes.
 	template <typename FOUNTAINSTREAM>

@@ -856,14 +856,18 @@ static void init_ccm(const uint8_t* rgb, md_state* md, co_ccm* ccm)
 	ccm->active = 1;
 }
 
-/* lib/encoder/Decoder.h:171-189 decode_fountain -> :60-118 do_decode */
-int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
-                       uint8_t* chunks, uint32_t* good_mask)
+/* lib/encoder/Decoder.h:60-118 do_decode. plain == 0: behind decode_fountain's aligned_stream (Decoder.h:171-189): `out` = 12 chunk slots,
+ * *good_mask = delivered chunks, returns the good bytes. plain != 0: Decoder::decode (Decoder.h:163-169) into a plain stream: `out` = the 60
+ * RS outputs back to back, a failed block as 125 zero bytes (reed_solomon_stream.h:62-74,96-107), block_ok[b] = 1 where libcorrect
+ * succeeded, returns what the stream's tellp() would (7500); no fountain header ever reaches the reader, so color_correction == 2
+ * keeps whatever matrix the thread already had (CimbReader.cpp:169-180). */
+static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
+                     int plain, uint8_t* outbuf, uint32_t* good_mask, uint8_t* block_ok)
 {
 	co_ccm local = {{0}, 0};
 	if (!ccm) ccm = &local;
-	memset(chunks, 0, (size_t)CO_CHUNKS_PER_FRAME * CO_CHUNK);
-	*good_mask = 0;
+	memset(outbuf, 0, (size_t)CO_CHUNKS_PER_FRAME * CO_CHUNK);
+	if (good_mask) *good_mask = 0;
 	if (w != IMG || h != IMG) return -1;   /* restatement covers the deskewed 1024x1024 case only */
 	ensure_pos();
 
@@ -899,9 +903,12 @@ int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int col
 	aligner_t al; memset(&al, 0, sizeof al);
 	md_state md; memset(&md, 0, sizeof md);
 	uint8_t out[CO_RS_DATA];
-	for (int b = 0; b < SYM_BYTES / CO_RS_BLOCK; ++b) {                    /* reed_solomon_stream.h:54-77 */
+	uint32_t dummy_mask = 0;
+	int nblock = 0;
+	for (int b = 0; b < SYM_BYTES / CO_RS_BLOCK; ++b, ++nblock) {          /* reed_solomon_stream.h:54-77 */
 		int r = co_rs_decode(symbuf + b * CO_RS_BLOCK, CO_RS_BLOCK, CO_RS_PARITY, out);
-		aligner_block(&al, r > 0, out, &md, chunks, good_mask);
+		if (plain) { if (r > 0) memcpy(outbuf + (size_t)nblock * CO_RS_DATA, out, CO_RS_DATA); if (block_ok) block_ok[nblock] = r > 0; }
+		else aligner_block(&al, r > 0, out, &md, outbuf, good_mask ? good_mask : &dummy_mask);
 	}
 
 	if (color_correction == 2) init_ccm(rgb, &md, ccm);                    /* Decoder.h:105 */
@@ -915,9 +922,22 @@ int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int col
 		colbuf[bitpos >> 3] |= (uint8_t)(bits << (6 - (bitpos & 7)));
 		t_colors[i] = (uint8_t)bits;
 	}
-	for (int b = 0; b < COL_BYTES / CO_RS_BLOCK; ++b) {
+	for (int b = 0; b < COL_BYTES / CO_RS_BLOCK; ++b, ++nblock) {
 		int r = co_rs_decode(colbuf + b * CO_RS_BLOCK, CO_RS_BLOCK, CO_RS_PARITY, out);
-		aligner_block(&al, r > 0, out, &md, chunks, good_mask);
+		if (plain) { if (r > 0) memcpy(outbuf + (size_t)nblock * CO_RS_DATA, out, CO_RS_DATA); if (block_ok) block_ok[nblock] = r > 0; }
+		else aligner_block(&al, r > 0, out, &md, outbuf, good_mask ? good_mask : &dummy_mask);
 	}
-	return (int)al.total;
+	return plain ? nblock * CO_RS_DATA : (int)al.total;
+}
+
+int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
+                       uint8_t* chunks, uint32_t* good_mask)
+{
+	return do_decode(rgb, w, h, preprocess, color_correction, ccm, 0, chunks, good_mask, NULL);
+}
+
+int co_decode_plain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
+                    uint8_t* bytes, uint8_t* block_ok)
+{
+	return do_decode(rgb, w, h, preprocess, color_correction, ccm, 1, bytes, NULL, block_ok);
 }

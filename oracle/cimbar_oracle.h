@@ -63,6 +63,11 @@ void co_ccm_transform(const float m[9], float r, float g, float b, float out3[3]
 int co_decode_fountain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
                        uint8_t* chunks, uint32_t* good_mask);
 
+/* Decoder::decode (Decoder.h:163-169) for one frame into a plain stream: bytes = 60 x 125 RS outputs, a failed block as zeros
+ * (reed_solomon_stream.h:62-74,96-107); block_ok (60 bytes, may be NULL) = 1 where libcorrect succeeded. Returns 7500. */
+int co_decode_plain(const uint8_t* rgb, int w, int h, int preprocess, int color_correction, co_ccm* ccm,
+                    uint8_t* bytes, uint8_t* block_ok);
+
 /* stage outputs of the last co_decode_fountain call on this thread (for stage-level parity tests) */
 const uint8_t* co_last_symbols(void);   /* CO_CELLS bytes, by cell index */
 const uint8_t* co_last_colors(void);    /* CO_CELLS bytes, by cell index */

@@ -74,6 +74,26 @@ def oracle_decode(rgb, preprocess=0, cc=2, ccm=None):
     return r, chunks, mask.value, ccm
 
 
+def oracle_decode_plain(rgb, preprocess=0, cc=2, ccm=None):
+    """co_decode_plain (Decoder::decode, the --no-fountain path) -> (ret, bytes (7500,), block_ok (60,), ccm struct)."""
+    L = oracle_lib()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    data = np.zeros(7500, np.uint8)
+    ok = np.zeros(60, np.uint8)
+    if ccm is None:
+        ccm = CoCcm()
+    r = L.co_decode_plain(P(rgb), rgb.shape[1], rgb.shape[0], int(preprocess), int(cc), ctypes.byref(ccm), P(data), P(ok))
+    return r, data, ok, ccm
+
+
+def ref_decode_plain(rgb, preprocess=0, cc=2, reset_ccm=1):
+    L = ref_lib()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    data = np.zeros(7500, np.uint8)
+    r = L.ref_decode_plain(P(rgb), rgb.shape[1], rgb.shape[0], int(preprocess), int(cc), int(reset_ccm), P(data))
+    return r, data
+
+
 def oracle_stage(rgb_unused=None):
     """symbols, colours, drifted positions of the last oracle_decode call on this thread."""
     L = oracle_lib()

@@ -223,6 +223,22 @@ int ref_decode_fountain(const uint8_t* rgb, unsigned w, unsigned h, int preproce
 	return (int)res;
 }
 
+// Decoder::decode (Decoder.h:163-169) on one RGB8 frame into a std::stringstream, the way `./cimbar --no-fountain` writes its
+// output file (cimbar.cpp:270-272): 60 RS outputs back to back, a failed block as 125 zero bytes. Returns the reference's return
+// value (the stream's tellp after the frame); bytes must hold 7500.
+int ref_decode_plain(const uint8_t* rgb, unsigned w, unsigned h, int preprocess, int color_correction, int reset_ccm, uint8_t* bytes)
+{
+	if (reset_ccm) reset_thread_ccm();
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	Decoder dec;
+	std::stringstream ss;
+	unsigned res = dec.decode(img, ss, preprocess != 0, color_correction);
+	const std::string out = ss.str();
+	std::memset(bytes, 0, 7500);
+	std::memcpy(bytes, out.data(), std::min<size_t>(out.size(), 7500));
+	return (int)res;
+}
+
 // The literal public entry point, writing into an escrow_buffer_writer exactly like cimbard_scan_extract_decode
 // (cimbar_recv_js.cpp:160-188). Returns buffers_in_use()*625; chunks packed contiguously.
 int ref_decode_fountain_escrow(const uint8_t* rgb, unsigned w, unsigned h, int preprocess, int color_correction, int reset_ccm,

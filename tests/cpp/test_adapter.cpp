@@ -66,6 +66,14 @@ int main(int argc, char** argv)
 	CHECK(sink2.bytes == sink.bytes);
 	for (uint32_t m : dec.last_masks()) CHECK(m == 0xFFF);
 
+	// Decoder::decode into a plain stream (cimbar.cpp:270-272): all 7500 bytes of every frame, tellp() as the return value
+	collecting_sink plain(0);
+	for (int f = 0; f < n; ++f) {
+		cimbar_amd::image_view img{frames.data() + FR * f, 1024, 1024, 1024 * 3};
+		CHECK(dec.decode(img, plain) == 7500u * (unsigned)(f + 1));
+	}
+	CHECK(plain.bytes == sink.bytes);   // clean frames: the RS outputs back to back are the fountain chunks back to back
+
 	// chunk-size mismatch: decode, report the bytes, feed nothing (Decoder.h:180-185)
 	collecting_sink wrong(600);
 	cimbar_amd::image_view img0{frames.data(), 1024, 1024, 0};

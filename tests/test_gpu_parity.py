@@ -118,3 +118,32 @@ def test_decode_frame_and_fountain_surface(hip_decoder, synth):
 def test_bad_arguments(hip_decoder):
     with pytest.raises(D.CimbarHipError):
         hip_decoder.decode_frame(np.zeros((512, 512, 3), np.uint8))
+
+
+@pytest.mark.parametrize("pre", [0, 1])
+def test_plain_decode_matches_oracle(hip_decoder, synth, pre):
+    """cimbar_hip_decode_plain_batch = Decoder::decode (--no-fountain): RS outputs back to back, failed blocks zeroed, and with
+    color_correction 2 no matrix of its own (no fountain header reaches the reader): frames reuse the carried one."""
+    names, frames = zip(*F.distorted_set(synth))
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    hip_decoder.reset_ccm()
+    total, data, ok = hip_decoder.decode_plain_batch(frames, should_preprocess=pre)
+    assert total == 7500 * n
+    ccm = pyref.CoCcm()
+    for k in range(n):
+        r, want, wok, ccm = pyref.oracle_decode_plain(frames[k], pre, 2, ccm)
+        assert r == 7500
+        assert (ok[k] == wok).all(), f"{names[k]}: RS block flags differ"
+        assert (data[k] == want).all(), f"{names[k]}: bytes differ"
+    # a carried matrix (left by a fountain decode on this context) is used by the plain path, like the reference's thread_local
+    _, clean = F.clean_frames(synth, 1, seed=8)
+    tinted = F.add_noise(clean[0], 30, 1)
+    hip_decoder.reset_ccm()
+    hip_decoder.decode_frame(tinted)                       # leaves a CCM behind
+    assert hip_decoder.get_ccm()[0]
+    _, d1, ok1 = hip_decoder.decode_plain_batch(tinted[None])
+    occ = pyref.CoCcm()
+    pyref.oracle_decode(tinted, 0, 2, occ)
+    _, w1, wok1, _ = pyref.oracle_decode_plain(tinted, 0, 2, occ)
+    assert (d1[0] == w1).all() and (ok1[0] == wok1).all()

@@ -102,3 +102,15 @@ def test_escrow_writer_entry_point(ref, synth):
     buf = np.zeros(7500, np.uint8)
     assert ref.ref_decode_fountain_escrow(P(np.ascontiguousarray(frames[0])), 1024, 1024, 0, 2, 1, P(buf)) == 7500
     assert (buf == payload[0]).all()
+
+
+@pytest.mark.parametrize("pre", [0, 1])
+def test_plain_decode_no_fountain_path(ref, oracle, synth, pre):
+    """Decoder::decode into a plain stream (cimbar.cpp:270-272): failed RS blocks become 125 zero bytes, tellp() is the return value"""
+    for name, fr in F.distorted_set(synth):
+        r, want = pyref.ref_decode_plain(fr, pre, 2, 1)
+        r2, got, ok, _ = pyref.oracle_decode_plain(fr, pre, 2)
+        assert r == r2 == 7500, name
+        assert (got == want).all(), name
+        blocks = got.reshape(60, 125)
+        assert all(ok[b] or not blocks[b].any() for b in range(60)), name
