@@ -3,8 +3,9 @@ own sources + cv-shim) on the deterministic input set of tests/frames.py. Commit
 neither /root/reference nor oracle/_ref.
 
 For every case: sha256 of the input frame (guards input regeneration), the reference's return value and chunk mask, sha256
-of the 12x625 chunk slots, of the packed bitplane, of the flood-ordered visit list (cell, x, y, symbol) and the colour-
-correction matrix left in the thread_local after the frame (raw float32 bits).
+of the 12x625 chunk slots, of the packed bitplane, of the flood-ordered visit list (cell, x, y, symbol), the colour-
+correction matrix left in the thread_local after the frame (raw float32 bits), and the return value + sha256 of the 7500
+bytes Decoder::decode (the --no-fountain path) writes for the same frame from a fresh thread state.
 """
 import ctypes
 import hashlib
@@ -35,7 +36,10 @@ def run_case(L, frame, pre, cc):
     plane = np.zeros(131072, np.uint8)
     visit = np.zeros(4 * 12400, np.int32)
     L.ref_symbol_pass(P(frame), 1024, 1024, pre, P(plane), P(visit))
+    plain = np.zeros(7500, np.uint8)
+    pr = L.ref_decode_plain(P(frame), 1024, 1024, pre, cc, 1, P(plain))      # Decoder::decode, fresh thread state
     return {"input_sha256": sha(frame), "ret": int(r), "mask": int(mask.value), "chunks_sha256": sha(chunks),
+            "plain_ret": int(pr), "plain_sha256": sha(plain),
             "bitplane_sha256": sha(plane), "visit_sha256": sha(visit), "ccm_active": int(active),
             "ccm_bits": [int(np.float32(x).view(np.uint32)) for x in m]}
 

@@ -37,3 +37,6 @@ def test_hip_matches_reference_fixture(case, golden_inputs, hip_decoder):
     assert int(active) == case["ccm_active"]
     if active:
         assert [int(x) for x in m.reshape(-1).view(np.uint32)] == case["ccm_bits"]
+    hip_decoder.reset_ccm()
+    pr, plain, _ = hip_decoder.decode_plain_batch(frame[None], bool(case["preprocess"]), case["color_correction"])   # Decoder::decode
+    assert pr == case["plain_ret"] and sha(plain[0]) == case["plain_sha256"]

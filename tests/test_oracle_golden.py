@@ -141,6 +141,8 @@ def test_oracle_matches_reference_fixture(case, golden_inputs, oracle):
     visit = np.zeros(4 * 12400, np.int32)
     assert oracle.co_symbol_pass(P(plane), P(visit), None) == 12400
     assert sha(visit) == case["visit_sha256"]
+    pr, plain, _, _ = pyref.oracle_decode_plain(frame, case["preprocess"], case["color_correction"])   # Decoder::decode
+    assert pr == case["plain_ret"] and sha(plain) == case["plain_sha256"]
 
 
 def test_rs_vectors_from_libcorrect(oracle):
