@@ -605,7 +605,7 @@ constexpr int HEAP_LDS = CIMBAR_HEAP_LDS;  // heap slots held in LDS (40 KiB; a 
                                  // spill to the global scratch under the same indices (tests build a second library with
                                  // CIMBAR_HEAP_LDS=1024 so that the spill path runs on ordinary frames)
 struct FloodScratch {
-	uint32_t* heap;      // [F][HEAP_CAP], only indices >= HEAP_LDS are ever touched
+	uint32_t* heap;      // [FLOOD_GRID][HEAP_CAP] one spill area per workgroup; only indices >= HEAP_LDS are ever touched
 };
 
 __device__ __forceinline__ uint32_t cool_enc(uint32_t c) { return c == 0xFEu ? 0u : (c == 0xFFu ? 2u : c); }   // real values: 1,3,4,5,7
@@ -790,7 +790,7 @@ __device__ __forceinline__ int seed_slot(int i)
 constexpr int FLOOD_GRID = 512;   // state + heap = 65 KiB of LDS: two workgroups per CU
 __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane, Tables tb, FloodScratch sc,
                                               const uint32_t* __restrict__ flood_flag, uint8_t* __restrict__ symbols,
-                                              int8_t* __restrict__ drift, int f0, int nframes)
+                                              int8_t* __restrict__ drift, int f0, int nframes, int area0)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t s_state[NCELLS + 8];
 	__shared__ uint32_t s_heap[HEAP_LDS];
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 			for (int i = lane; i < (NCELLS + 8) / 8; i += 64) reinterpret_cast<uint4*>(s_state)[i] = ff;
 			if (lane < 8) s_seed[lane] = (0xFEu << 16) | DEFAULT_D;
 		}
-		WaveHeap hp{(lds_u32*)s_heap, sc.heap + (size_t)f * HEAP_CAP, 0};
+		WaveHeap hp{(lds_u32*)s_heap, sc.heap + (size_t)(area0 + blockIdx.x) * HEAP_CAP, 0};   // spill scratch belongs to the workgroup, not the frame
 		__syncthreads();
 		{
 			const uint32_t last = NCELLS - 1;
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 			if (!more) break;
 		}
 #ifdef FLOOD_PROF
-		if (lane == 0) for (int k = 0; k < 10; ++k) { sc.heap[(size_t)f * HEAP_CAP + 2 * k] = (uint32_t)pt[k]; sc.heap[(size_t)f * HEAP_CAP + 2 * k + 1] = (uint32_t)(pt[k] >> 32); }
+		if (lane == 0) for (int k = 0; k < 10; ++k) { sc.heap[(size_t)(area0 + blockIdx.x) * HEAP_CAP + 2 * k] = (uint32_t)pt[k]; sc.heap[(size_t)(area0 + blockIdx.x) * HEAP_CAP + 2 * k + 1] = (uint32_t)(pt[k] >> 32); }
 #endif
 		// results of the cells that were visited (all of them, unless the grid were disconnected)
 		__syncthreads();
@@ -1961,7 +1961,7 @@ int ensure_capacity(cimbar_hip_ctx* ctx, int n)
 	HIPCHK(regrow(ctx->d_ccm_used, N * 10));
 	HIPCHK(regrow(ctx->d_chunks, N * FRAME_BYTES));
 	HIPCHK(regrow(ctx->d_masks, N));
-	HIPCHK(regrow(ctx->flood.heap, N * HEAP_CAP));
+	if (!ctx->flood.heap) HIPCHK(regrow(ctx->flood.heap, (size_t)FLOOD_GRID * HEAP_CAP));   // one spill area per resident flood workgroup
 	ctx->cap = n;
 	return 0;
 }
@@ -2010,8 +2010,12 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		if (part == 0) {
 			hipLaunchKernelGGL(k_symbols, dim3(DIM / K2_BLOCK_ROWS, m), dim3(256), 0, s, ctx->d_plane, ctx->tb, ctx->d_symbols, ctx->d_flood, fa);
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
-			hipLaunchKernelGGL(k_flood, dim3(m < FLOOD_GRID ? m : FLOOD_GRID), dim3(64), 0, s, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
-			                   ctx->d_drift, fa, m);
+			{
+				// the two halves of a split batch may run their flood kernels at the same time: each gets its own half of the spill areas
+				const int areas = split ? FLOOD_GRID / 2 : FLOOD_GRID, area0 = (split && s != st) ? FLOOD_GRID / 2 : 0;
+				hipLaunchKernelGGL(k_flood, dim3(m < areas ? m : areas), dim3(64), 0, s, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
+				                   ctx->d_drift, fa, m, area0);
+			}
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
 			hipLaunchKernelGGL((k_rs<4>), dim3((m * SYM_BLOCKS + 3) / 4), dim3(256), 0, s, ctx->d_symbols, ctx->tb, fa, m, 0, d_chunks, ctx->d_rs_ok, 0);
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;

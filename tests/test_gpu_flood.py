@@ -66,3 +66,20 @@ def test_single_frame_batches_and_repeat_calls(hip_decoder, synth):
         _, c1, m1 = hip_decoder.decode_batch(shifted[k:k + 1], color_correction=0)
         assert m1[0] == m3[k] and (c1[0] == c3[k]).all()
     assert (m3 == 0xFFF).all() and (c3.reshape(3, -1) == payload).all()
+
+
+def test_split_batch_floods_with_spilling_heaps(synth):
+    """a batch large enough to run as two half-batches on two streams: both halves' flood kernels spill at the same time"""
+    import torch
+    from libcimbar_amd import framegen
+    dev = torch.device("cuda", 0)
+    dec = D.HipDecoder(0, lib_path=hipbuild.OUT_SPILLTEST)
+    n = 160
+    payload = framegen.synth_payload(n, seed=11, device=dev)
+    frames = torch.roll(framegen.FrameSynth(dev).frames_from_payload(payload), shifts=(1, 2), dims=(1, 2)).contiguous()
+    chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+    dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    assert int(dec.tap(D.TAP_FLOOD, n).sum()) == n
+    assert bool((masks == 0xFFF).all()) and bool((chunks == payload).all())
