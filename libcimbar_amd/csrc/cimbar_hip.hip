@@ -1759,7 +1759,8 @@ __global__ void k_plane_bytes(const uint32_t* __restrict__ plane, uint8_t* __res
 struct cimbar_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t stream2 = nullptr;            // second half of a batch's tail kernels (see enqueue)
+	hipStream_t stream2 = nullptr;            // second half of a batch's tail kernels (see enqueue); pipelined batches: even ones
+	hipStream_t stream3 = nullptr;            // pipelined batches: odd ones
 	hipEvent_t ev_k1 = nullptr, ev_join = nullptr, ev_mid[8] = {};
 	int tail_split = 1, tail_parts = 2;
 	std::string err;
@@ -1779,6 +1780,17 @@ struct cimbar_hip_ctx {
 	FrameState* d_states = nullptr;
 	float* d_ccm_frames = nullptr;
 	float* d_ccm_used = nullptr;
+	// the pipelined entry point alternates between the scratch above and this second set, so that the threshold pass of batch
+	// k+1 can run while the rest of batch k is still reading its intermediates
+	struct AltScratch {
+		int cap = 0;
+		uint32_t* d_plane = nullptr; uint32_t* d_cellmean = nullptr; uint8_t* d_symbols = nullptr; uint8_t* d_colors = nullptr;
+		int8_t* d_drift = nullptr; uint32_t* d_flood = nullptr; uint8_t* d_rs_ok = nullptr; FrameState* d_states = nullptr;
+		float* d_ccm_frames = nullptr; float* d_ccm_used = nullptr;
+	} alt;
+	int pipe_set = 0;                 // which set the member pointers above currently are (0 / 1)
+	bool pipe_used[2] = {false, false};
+	hipEvent_t ev_pk1[2] = {}, ev_pdone[2] = {};
 	float* d_carry = nullptr;         // 10 floats
 	uint8_t* d_template = nullptr;    // encode half: empty frame (background, anchors, guides)
 	uint8_t* d_gen_log = nullptr;     // encode half: logs of the 30 low generator coefficients
@@ -1978,15 +1990,39 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+	if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
 	for (hipEvent_t e : {ctx->ev_k1, ctx->ev_join}) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->ev_mid) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : ctx->ev_pk1) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : ctx->ev_pdone) if (e) (void)hipEventDestroy(e);
+	fr(ctx->alt.d_plane); fr(ctx->alt.d_cellmean); fr(ctx->alt.d_symbols); fr(ctx->alt.d_colors); fr(ctx->alt.d_drift); fr(ctx->alt.d_flood);
+	fr(ctx->alt.d_rs_ok); fr(ctx->alt.d_states); fr(ctx->alt.d_ccm_frames); fr(ctx->alt.d_ccm_used);
 	delete ctx;
 }
 
-// enqueue the whole pipeline for n device-resident frames on stream `st`
-int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks, int plain = 0)
+// pipelined batches in flight use the scratch sets and the tail stream: anything else that touches them on `st` waits first
+int drain_pipeline_into(cimbar_hip_ctx* ctx, hipStream_t st)
 {
-	const bool tm = ctx->timing;
+	for (int k = 0; k < 2; ++k)
+		if (ctx->pipe_used[k]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[k], 0));   // (a completed event costs nothing to wait for)
+	return 0;
+}
+
+void swap_scratch_sets(cimbar_hip_ctx* ctx)
+{
+	std::swap(ctx->cap, ctx->alt.cap);
+	std::swap(ctx->d_plane, ctx->alt.d_plane); std::swap(ctx->d_cellmean, ctx->alt.d_cellmean); std::swap(ctx->d_symbols, ctx->alt.d_symbols);
+	std::swap(ctx->d_colors, ctx->alt.d_colors); std::swap(ctx->d_drift, ctx->alt.d_drift); std::swap(ctx->d_flood, ctx->alt.d_flood);
+	std::swap(ctx->d_rs_ok, ctx->alt.d_rs_ok); std::swap(ctx->d_states, ctx->alt.d_states); std::swap(ctx->d_ccm_frames, ctx->alt.d_ccm_frames);
+	std::swap(ctx->d_ccm_used, ctx->alt.d_ccm_used);
+	ctx->pipe_set ^= 1;
+}
+
+// enqueue the whole pipeline for n device-resident frames on stream `st`
+int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, int pre, int cc, uint8_t* d_chunks, uint32_t* d_masks, int plain = 0,
+            bool pipe = false)
+{
+	const bool tm = ctx->timing && !pipe;
 	int evi = 0;
 	auto mark = [&]() -> hipError_t { return tm ? hipEventRecord(ctx->ev[evi++], st) : hipSuccess; };
 	const dim3 cell_grid((NCELLS + 255) / 256, n);
@@ -2004,7 +2040,7 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 	// streams, so one half's serial phases and launch gaps are covered by the other half's kernels. The only cross-half dependency
 	// is the colour-correction carry: a frame with no matrix of its own takes the newest one of the frames before it, so the second
 	// half's colour pass waits for the first half's k_frame_mid. Stage timing uses the single-stream order.
-	const bool split = !tm && ctx->tail_split && n >= 64 * ctx->tail_parts;
+	const bool split = !tm && !pipe && ctx->tail_split && n >= 64 * ctx->tail_parts;
 	auto tail = [&](hipStream_t s, int fa, int m, int part) -> hipError_t {
 		// part 0: up to k_frame_mid, part 1: the rest
 		if (part == 0) {
@@ -2012,7 +2048,8 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
 			{
 				// the two halves of a split batch may run their flood kernels at the same time: each gets its own half of the spill areas
-				const int areas = split ? FLOOD_GRID / 2 : FLOOD_GRID, area0 = (split && s != st) ? FLOOD_GRID / 2 : 0;
+				const int areas = (split || pipe) ? FLOOD_GRID / 2 : FLOOD_GRID;
+				const int area0 = ((split && s != st) || (pipe && ctx->pipe_set)) ? FLOOD_GRID / 2 : 0;
 				hipLaunchKernelGGL(k_flood, dim3(m < areas ? m : areas), dim3(64), 0, s, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
 				                   ctx->d_drift, fa, m, area0);
 			}
@@ -2031,7 +2068,17 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		                   fa + m == n ? 1 : 0, plain);
 		return s == st ? mark() : hipSuccess;
 	};
-	if (!split) {
+	if (pipe) {
+		// the whole batch runs on one of the context's two streams (`st` here), the next batch on the other one: two independent
+		// queues, so K1 of one batch overlaps the short kernels of the other. The one thing that crosses over is the colour-
+		// correction carry (and the order of the results): this batch's colour pass waits for the previous batch's end.
+		const int set = ctx->pipe_set;
+		HIPCHK(tail(st, f0, n, 0));
+		if (ctx->pipe_used[set ^ 1]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[set ^ 1], 0));
+		HIPCHK(tail(st, f0, n, 1));
+		HIPCHK(hipEventRecord(ctx->ev_pdone[set], st));
+		ctx->pipe_used[set] = true;
+	} else if (!split) {
 		HIPCHK(tail(st, f0, n, 0));
 		HIPCHK(tail(st, f0, n, 1));
 	} else {
@@ -2084,9 +2131,12 @@ int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out)
 	auto fail = [&](int code) { destroy_ctx(ctx); return code; };
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	for (hipEvent_t* e : {&ctx->ev_k1, &ctx->ev_join})
 		if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	for (hipEvent_t& e : ctx->ev_mid) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	for (hipEvent_t& e : ctx->ev_pk1) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	for (hipEvent_t& e : ctx->ev_pdone) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	if (const char* v = std::getenv("CIMBAR_HIP_TAIL_SPLIT")) ctx->tail_split = std::atoi(v);
 	if (const char* v = std::getenv("CIMBAR_HIP_TAIL_PARTS")) { int k = std::atoi(v); if (k >= 2 && k <= 8 && k % 2 == 0) ctx->tail_parts = k; }
 	for (auto& e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
@@ -2105,6 +2155,7 @@ int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx)
 {
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	HIPCHK(hipSetDevice(ctx->device));
+	if (ctx->pipe_used[0] || ctx->pipe_used[1]) HIPCHK(hipDeviceSynchronize());   // pipelined batches still carry the matrix forward
 	HIPCHK(hipMemsetAsync(ctx->d_carry, 0, sizeof(float) * 10, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return 0;
@@ -2115,7 +2166,7 @@ int cimbar_hip_get_ccm(cimbar_hip_ctx* ctx, float out9[9])
 	if (!ctx || !out9) return CIMBAR_HIP_EINVAL;
 	float tmp[10];
 	HIPCHK(hipSetDevice(ctx->device));
-	HIPCHK(hipStreamSynchronize(ctx->stream));
+	HIPCHK(hipDeviceSynchronize());   // whatever stream the last batch ran on
 	HIPCHK(hipMemcpy(tmp, ctx->d_carry, sizeof tmp, hipMemcpyDeviceToHost));
 	std::memcpy(out9, tmp, sizeof(float) * 9);
 	return tmp[9] != 0.0f ? 1 : 0;
@@ -2135,6 +2186,7 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 	// work is ordered after whatever produced the frames there; the all-host path synchronises anyway and uses its own stream
 	const bool any_device = rgb_mem == CIMBAR_HIP_MEM_DEVICE || out_mem == CIMBAR_HIP_MEM_DEVICE;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
+	if (int r = drain_pipeline_into(ctx, st)) return r;
 	if (int r = ensure_capacity(ctx, n)) return r;
 
 	const uint8_t* d_rgb = rgb;
@@ -2161,6 +2213,35 @@ int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, 
 	return (int64_t)total;
 }
 
+int cimbar_hip_decode_batch_pipelined(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int should_preprocess, int color_correction,
+                                      uint8_t* chunks, uint32_t* masks, void* hip_stream)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	if (!rgb || !chunks || !masks || n <= 0) { ctx->err = "decode_batch_pipelined: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	swap_scratch_sets(ctx);
+	const int set = ctx->pipe_set;
+	hipStream_t own = set ? ctx->stream3 : ctx->stream2;
+	// the frames are whatever `hip_stream` has produced up to here
+	HIPCHK(hipEventRecord(ctx->ev_pk1[set], st));
+	HIPCHK(hipStreamWaitEvent(own, ctx->ev_pk1[set], 0));
+	// (this set's intermediates belong to the batch issued two calls ago on the same stream: stream order keeps them apart)
+	if (int r = ensure_capacity(ctx, n)) return r;
+	return enqueue(ctx, own, rgb, n, should_preprocess, color_correction, chunks, masks, 0, true);
+}
+
+int cimbar_hip_pipeline_wait(cimbar_hip_ctx* ctx, void* hip_stream, int keep_newest)
+{
+	if (!ctx) return CIMBAR_HIP_EINVAL;
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	const int newest = ctx->pipe_set, older = newest ^ 1;
+	if (ctx->pipe_used[older]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[older], 0));
+	if (!keep_newest && ctx->pipe_used[newest]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[newest], 0));
+	return 0;
+}
+
 int64_t cimbar_hip_decode_plain_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
                                       int color_correction, uint8_t* bytes, uint8_t* block_ok, int out_mem, void* hip_stream)
 {
@@ -2173,6 +2254,7 @@ int64_t cimbar_hip_decode_plain_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, i
 	HIPCHK(hipSetDevice(ctx->device));
 	const bool any_device = rgb_mem == CIMBAR_HIP_MEM_DEVICE || out_mem == CIMBAR_HIP_MEM_DEVICE;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
+	if (int r = drain_pipeline_into(ctx, st)) return r;
 	if (int r = ensure_capacity(ctx, n)) return r;
 	const uint8_t* d_rgb = rgb;
 	if (rgb_mem == CIMBAR_HIP_MEM_HOST) {
@@ -2227,6 +2309,7 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
 	HIPCHK(hipSetDevice(ctx->device));
 	const bool any_device = payload_mem == CIMBAR_HIP_MEM_DEVICE || rgb_mem == CIMBAR_HIP_MEM_DEVICE;
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : (any_device ? (hipStream_t)nullptr : ctx->stream);
+	if (int r = drain_pipeline_into(ctx, st)) return r;
 	if (int r = ensure_capacity(ctx, n)) return r;
 	const uint8_t* d_payload = payload;
 	if (payload_mem == CIMBAR_HIP_MEM_HOST) {

@@ -59,6 +59,10 @@ def load_library(path=None):
     lib.cimbar_hip_decode_batch.restype = i64
     lib.cimbar_hip_decode_plain_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.cimbar_hip_decode_plain_batch.restype = i64
+    lib.cimbar_hip_decode_batch_pipelined.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.cimbar_hip_decode_batch_pipelined.restype = i32
+    lib.cimbar_hip_pipeline_wait.argtypes = [vp, vp, i32]
+    lib.cimbar_hip_pipeline_wait.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -162,6 +166,19 @@ class HipDecoder:
                                                ctypes.c_void_p(stream) if stream else None)
         self._check(rc, "cimbar_hip_decode_batch(device)")
         return int(rc)
+
+    def decode_batch_pipelined(self, frames_ptr, n, chunks_ptr, masks_ptr, should_preprocess=False, color_correction=2, stream=None):
+        """Like decode_batch_device, but only the threshold pass runs on `stream`: the rest of the batch overlaps the next batch's
+        threshold pass. Outputs are valid once a later pipeline_wait() on a stream has been reached; at most two batches in flight."""
+        rc = self._lib.cimbar_hip_decode_batch_pipelined(self._ctx, ctypes.c_void_p(frames_ptr), int(n), int(bool(should_preprocess)),
+                                                         int(color_correction), ctypes.c_void_p(chunks_ptr), ctypes.c_void_p(masks_ptr),
+                                                         ctypes.c_void_p(stream) if stream else None)
+        self._check(rc, "cimbar_hip_decode_batch_pipelined")
+
+    def pipeline_wait(self, stream=None, keep_newest=False):
+        """`stream` waits for the pipelined batches issued so far (all but the newest one with keep_newest)."""
+        self._check(self._lib.cimbar_hip_pipeline_wait(self._ctx, ctypes.c_void_p(stream) if stream else None, int(bool(keep_newest))),
+                    "cimbar_hip_pipeline_wait")
 
     # ------------------------------------------------------------------ the reference's operator surface
     def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):

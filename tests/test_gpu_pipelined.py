@@ -1,0 +1,70 @@
+"""GPU: the pipelined entry point (threshold pass of batch k+1 overlapping the rest of batch k) returns exactly what the ordinary
+one does for the same sequence of batches, including the colour-correction carry from batch to batch and the flood pass."""
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import decoder as D
+from libcimbar_amd import modeb
+from tests import frames as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_sequence_equals_ordinary_sequence(synth):
+    dev = torch.device("cuda", 0)
+    payload, clean = F.clean_frames(synth, 6, seed=77)
+    blank = np.zeros_like(clean[0])
+    # batch 1 ends with a frame that has no matrix of its own; batch 2 starts with one: it must inherit batch 1's last matrix
+    batches = [
+        [clean[0], F.add_noise(clean[1], 40, 1), F.shift(clean[2], 2, 1)],
+        [blank, F.add_noise(clean[3], 60, 2), clean[4]],
+        [blank, F.shift(clean[5], -1, 2), F.add_noise(clean[0], 25, 3)],
+        [F.add_noise(clean[2], 90, 4), blank, blank],
+    ]
+    tens = [torch.from_numpy(np.ascontiguousarray(np.stack(b))).to(dev) for b in batches]
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(pipelined):
+        dec = D.HipDecoder(0)
+        outs = [(torch.zeros((3, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((3,), dtype=torch.int32, device=dev)) for _ in tens]
+        cols = []
+        for t, (c, m) in zip(tens, outs):
+            if pipelined:
+                dec.decode_batch_pipelined(t.data_ptr(), 3, c.data_ptr(), m.data_ptr(), False, 2, st)
+            else:
+                dec.decode_batch_device(t.data_ptr(), 3, c.data_ptr(), m.data_ptr(), False, 2, st)
+                torch.cuda.synchronize()
+                cols.append(dec.tap(D.TAP_COLORS, 3).copy())
+        if pipelined:
+            dec.pipeline_wait(st)
+        torch.cuda.synchronize()
+        res = [(c.cpu().numpy(), m.cpu().numpy()) for c, m in outs]
+        ccm = dec.get_ccm()
+        dec.close()
+        return res, ccm, cols
+
+    want, wccm, _ = run(False)
+    got, gccm, _ = run(True)
+    for k, ((wc, wm), (gc, gm)) in enumerate(zip(want, got)):
+        assert (wm == gm).all(), f"batch {k}: masks {wm} vs {gm}"
+        assert (wc == gc).all(), f"batch {k}: chunk bytes differ"
+    assert wccm[0] == gccm[0] and wccm[1].tobytes() == gccm[1].tobytes()
+
+
+def test_pipelined_then_ordinary_calls_mix(synth):
+    dev = torch.device("cuda", 0)
+    payload, clean = F.clean_frames(synth, 2, seed=5)
+    t = torch.from_numpy(np.ascontiguousarray(clean)).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    dec = D.HipDecoder(0)
+    c = [torch.zeros((2, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev) for _ in range(3)]
+    m = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(3)]
+    dec.decode_batch_pipelined(t.data_ptr(), 2, c[0].data_ptr(), m[0].data_ptr(), False, 2, st)
+    dec.decode_batch_pipelined(t.data_ptr(), 2, c[1].data_ptr(), m[1].data_ptr(), False, 2, st)
+    dec.decode_batch_device(t.data_ptr(), 2, c[2].data_ptr(), m[2].data_ptr(), False, 2, st)   # waits for the pipeline by itself
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert bool((m[k] == 0xFFF).all()) and (c[k].cpu().numpy() == payload).all()
+    total, chunks, masks = dec.decode_batch(clean)   # host entry point after pipelined use
+    assert total == 15000 and (chunks.reshape(2, -1) == payload).all()
