@@ -24,6 +24,7 @@ EXPORTS = (
     "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
+    "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait",
 )
 
 
