@@ -4,16 +4,20 @@
 // Decoder::decode_fountain (src/lib/encoder/Decoder.h:171-189). See include/cimbar_hip.h for the boundary and
 // DESIGN.md for the data layout / roofline notes. Paths in comments are relative to /root/reference/src.
 //
-// Pipeline (all on one HIP stream, a batch of F frames per launch; nothing here is GEMM-shaped, so no MFMA):
+// Pipeline (a batch of F frames per launch; nothing here is GEMM-shaped, so no MFMA). One call = K1, then the chain of short
+// kernels, on the caller's stream (large batches: the chain as two half-batches on two streams); the pipelined entry point
+// alternates whole batches between two context-owned streams. See enqueue() and DESIGN.md "Launch structure".
 //   K1 k_threshold      RGB -> gray -> (sharpen) -> 5x5|7x7 box-mean threshold -> bitplane   [HBM-read bound]
 //   K2 k_symbols        every cell at drift (0,0): 10x10 bit window -> 5|9 shifted 8x8 hashes -> popcount match;
 //                       flags the frame if any cell prefers a shifted window (order then matters -> K2b)
-//   K2b k_flood         exact emulation of the reference's priority-flood order + drift, one wavefront per flagged frame
+//   K2b k_flood         exact emulation of the reference's priority-flood order + drift, one wavefront per flagged frame,
+//                       heap and per-cell state in LDS
 //   K3 k_rs             de-interleave + RS(155,125) decode, one block per wavefront (symbols: 40 blocks)
 //   K4 k_frame_mid      aligned_stream bookkeeping for the symbol chunks, fountain-header prediction, CCM derivation
 //   K5 k_colors         6x6 cell mean -> CCM -> palette classifier
 //   K3 k_rs             (colours: 20 blocks)
 //   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots, CCM carry-out
+//   E1 k_rs_encode / E2 k_render   the encode half (Encoder::encode_next): RS encode + tile render
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
