@@ -255,7 +255,13 @@ template <int RAD, bool PRE>
 #ifndef K1_WAVES
 #define K1_WAVES 3
 #endif
-__global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
+#ifndef K1_PRE_WAVES
+#define K1_PRE_WAVES 2
+#endif
+#ifndef K1_PRE_DEPTH
+#define K1_PRE_DEPTH 4
+#endif
+__global__ __launch_bounds__(256, PRE ? K1_PRE_WAVES : K1_WAVES) void k_threshold(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ plane,
                                                                 uint32_t* __restrict__ cellmean, uint32_t* __restrict__ flood_flag, int f0)
 {
 	constexpr int RING = 2 * RAD + 2;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : K1_WAVES) void k_threshold(const uin
 #ifndef K1_DEPTH
 #define K1_DEPTH 3
 #endif
-	constexpr int DEPTH = PRE ? 4 : K1_DEPTH;   // rows in flight per wave; RING % DEPTH == 0 keeps the buffer roles static after unrolling
+	constexpr int DEPTH = PRE ? K1_PRE_DEPTH : K1_DEPTH;   // rows in flight per wave; RING % DEPTH == 0 keeps the buffer roles static after unrolling
 	static_assert(RING % DEPTH == 0, "prefetch depth must divide the ring size");
 	uint32_t buf[DEPTH][12];          // row t lives in buf[t % DEPTH] and is refilled with row t+DEPTH as soon as it is consumed
 	auto bounded = [&](int y) { return clampy(dir > 0 ? (y < y_stop ? y : y_stop) : (y > y_stop ? y : y_stop)); };
