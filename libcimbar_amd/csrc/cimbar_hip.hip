@@ -605,9 +605,9 @@ __global__ __launch_bounds__(256) void k_symbols(const uint32_t* __restrict__ pl
 // strictly smaller priority than the cell's previous ones, so the entry that pops first IS the latest instruction):
 //   prio(7) << 25 | cell(14) << 11 | dx+8 (4) << 7 | dy+8 (4) << 3 | cooldown code (3)
 // The eight seed cells are the exception (their seed entry pops with priority 0/1 but must use the latest accepted offer, if
-// any): their current instruction lives in s_seed[]. s_state[cell] (u16) = best offered priority + 1, 0x7FFF (no offer yet), or, once
-// visited, 0x8000 | symbol | dx+8 << 4 | dy+8 << 9 -- the results stay in LDS until the frame is done, so the only global
-// accesses inside the loop are the two prefetches.
+// any): their current instruction lives in s_seed[]. s_state[cell] (u8) = best offered priority + 1, 0x7F (no offer yet), or, once
+// visited, 0x80 | symbol. The symbols go out when the frame is done; the position the colour pass reads is one fire-and-forget
+// 2-byte store per step (nothing in the loop waits for stores: the only loads are the two prefetches, consumed a pop later).
 #ifndef CIMBAR_HEAP_LDS
 #define CIMBAR_HEAP_LDS 10240
 #endif
@@ -797,12 +797,12 @@ __device__ __forceinline__ int seed_slot(int i)
 	return s;
 }
 
-constexpr int FLOOD_GRID = 512;   // state + heap = 65 KiB of LDS: two workgroups per CU
+constexpr int FLOOD_GRID = 768;   // state + heap = 52 KiB of LDS: three workgroups per CU
 __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane, Tables tb, FloodScratch sc,
                                               const uint32_t* __restrict__ flood_flag, uint8_t* __restrict__ symbols,
                                               int8_t* __restrict__ drift, int f0, int nframes, int area0)
 {
-	__shared__ __attribute__((aligned(16))) uint16_t s_state[NCELLS + 8];
+	__shared__ __attribute__((aligned(16))) uint8_t s_state[NCELLS + 16];
 	__shared__ uint32_t s_heap[HEAP_LDS];
 	__shared__ uint32_t s_seed[8];                                           // prio << 16 | (dx+8) << 7 | (dy+8) << 3 | cooldown code
 	const int lane = threadIdx.x;
@@ -814,8 +814,8 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 		const uint32_t* pl = plane + (size_t)f * PLANE_WORDS;
 		__syncthreads();   // the previous frame of this workgroup is completely done with the LDS
 		{
-			uint4 ff; ff.x = ff.y = ff.z = ff.w = 0x7FFF7FFFu;
-			for (int i = lane; i < (NCELLS + 8) / 8; i += 64) reinterpret_cast<uint4*>(s_state)[i] = ff;
+			uint4 ff; ff.x = ff.y = ff.z = ff.w = 0x7F7F7F7Fu;
+			for (int i = lane; i < (NCELLS + 16) / 16; i += 64) reinterpret_cast<uint4*>(s_state)[i] = ff;
 			if (lane < 8) s_seed[lane] = (0xFEu << 16) | DEFAULT_D;
 		}
 		WaveHeap hp{(lds_u32*)s_heap, sc.heap + (size_t)(area0 + blockIdx.x) * HEAP_CAP, 0};   // spill scratch belongs to the workgroup, not the frame
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 				e = (uint32_t)__builtin_amdgcn_readfirstlane((int)topv);
 				PROF_ADD(7);
 				const int idx = (int)((e >> 11) & 0x3FFFu);
-				const bool fresh = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_state[idx]) & 0x8000u) == 0;
+				const bool fresh = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_state[idx]) & 0x80u) == 0;
 				if (fresh) {
 					di = e & 0x7FFu; prev_prio = e >> 25;
 					const int slot = seed_slot(idx);
@@ -931,8 +931,12 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 			ndx = ndx > 7 ? 7 : (ndx < -7 ? -7 : ndx);
 			ndy = ndy > 7 ? 7 : (ndy < -7 ? -7 : ndy);
 			const uint32_t ncool = calc_cooldown(cooldown, w);
-			// visited: the symbol and the position the colour pass reads (CimbReader.cpp:158-160 pos.x/y), each offset in [-8, 8]
-			if (lane == 0) s_state[i] = (uint16_t)(0x8000u | bits | ((uint32_t)(ddx + bdx + 8) << 4) | ((uint32_t)(ddy + bdy + 8) << 9));
+			// visited + the symbol; the position the colour pass reads (CimbReader.cpp:158-160 pos.x/y) goes straight to memory
+			if (lane == 0) {
+				s_state[i] = (uint8_t)(0x80u | bits);
+				*reinterpret_cast<uint16_t*>(drift + ((size_t)f * NCELLS + i) * 2) =
+				    (uint16_t)(((uint32_t)(ddx + bdx) & 0xFFu) | (((uint32_t)(ddy + bdy) & 0xFFu) << 8));
+			}
 
 			// ---- FloodDecodePositions::update(): lanes 0-3 the adjacent cells (right, left, bottom, top), 4-7 the horizontal
 			// "horizon" (:93-111), 8-11 the vertical one (:113-129), in the reference's offer order. No cell occurs twice in
@@ -943,10 +947,10 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 			const bool want = lane < 12 && ((lanes_ok >> (lane & 15)) & 1u) && cand >= 0;
 			// update_adjacents (:69-83): still to decode and strictly better than what the cell was offered before
 			const uint32_t cst = s_state[want ? (int)cand : 0];
-			const bool accept = want && !(cst & 0x8000u) && cst >= error_distance + 2u;
+			const bool accept = want && !(cst & 0x80u) && cst >= error_distance + 2u;
 			const uint32_t dcode = ((uint32_t)(ndx + 8) << 7) | ((uint32_t)(ndy + 8) << 3) | cool_enc(ncool);
 			if (accept) {
-				s_state[cand] = (uint16_t)(error_distance + 1u);
+				s_state[cand] = (uint8_t)(error_distance + 1u);
 				const int sl = seed_slot((int)cand);
 				if (sl >= 0) s_seed[sl] = (error_distance << 16) | dcode;
 			}
@@ -972,14 +976,11 @@ __global__ __launch_bounds__(64) void k_flood(const uint32_t* __restrict__ plane
 #ifdef FLOOD_PROF
 		if (lane == 0) for (int k = 0; k < 10; ++k) { sc.heap[(size_t)(area0 + blockIdx.x) * HEAP_CAP + 2 * k] = (uint32_t)pt[k]; sc.heap[(size_t)(area0 + blockIdx.x) * HEAP_CAP + 2 * k + 1] = (uint32_t)(pt[k] >> 32); }
 #endif
-		// results of the cells that were visited (all of them, unless the grid were disconnected)
+		// symbols of the cells that were visited (all of them, unless the grid were disconnected)
 		__syncthreads();
 		for (int c = lane; c < NCELLS; c += 64) {
 			const uint32_t v = s_state[c];
-			if (!(v & 0x8000u)) continue;
-			symbols[(size_t)f * NCELLS + c] = (uint8_t)(v & 15u);
-			drift[((size_t)f * NCELLS + c) * 2] = (int8_t)((int)((v >> 4) & 31u) - 8);
-			drift[((size_t)f * NCELLS + c) * 2 + 1] = (int8_t)((int)((v >> 9) & 31u) - 8);
+			if (v & 0x80u) symbols[(size_t)f * NCELLS + c] = (uint8_t)(v & 15u);
 		}
 	}
 }
