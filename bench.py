@@ -115,8 +115,8 @@ def cpu_baseline(frames_host, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (BASELINE configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -142,55 +142,60 @@ def main():
     n = args.frames
     dec = HipDecoder(local_rank)
     payload, frames = make_frames(n, dev, seed=1234 + rank, dec=dec)
-    # two sets of output buffers: with N > 1 the gather of step k (RCCL, its own stream) overlaps the decode of step k+1
+    # The batches form a continuous stream, so the library's pipelined entry point is used: up to D = pipeline_depth steps are in flight
+    # on the context's own streams, the threshold pass of one overlapping the short kernels of the others (colour-correction carry-over
+    # still in batch order). A step's outputs are consumed D-1 steps later: with N > 1 the RCCL gather of step k-D+1 is issued right
+    # after step k has been enqueued. D output buffer sets (and, on rank 0, D gather destinations).
+    D = 1 if args.no_pipeline else dec.pipeline_depth
+    NB = max(D, 2)
     outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev))
-            for _ in range(2)]
+            for _ in range(NB)]
     gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev),
-                 torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(2)]
-    pending = [[], []]
+                 torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(NB)]
+    pending = [[] for _ in range(NB)]
+    fresh = [False] * NB              # buffer set b holds a decoded step that has not been gathered yet
     stream = torch.cuda.current_stream(dev)
     step_no = [0]
-
-    # The batches form a continuous stream, so the library's pipelined entry point is used: the threshold pass of step k+1 runs on this
-    # stream while the rest of step k finishes on the context's own stream (colour-correction carry-over still in batch order). A
-    # step's outputs are consumed one step later: with N > 1 the gather of step k-1 is issued after step k has been enqueued.
-    fresh = [False, False]            # buffer set k holds a decoded step that has not been gathered yet
     last = [None]
 
-    def gather_of(k):
-        if not fresh[k]:
+    def gather_of(b):
+        if not fresh[b]:
             return
-        fresh[k] = False
-        chunks, masks = outs[k]
-        all_c, all_m, pending[k] = multigpu.gather_chunks(chunks, masks, dst=0, out=gathered[k], async_op=True)
+        fresh[b] = False
+        chunks, masks = outs[b]
+        all_c, all_m, pending[b] = multigpu.gather_chunks(chunks, masks, dst=0, out=gathered[b], async_op=True)
         last[0] = (all_c, all_m)
 
     def step():
-        k = step_no[0] & 1
+        k = step_no[0]
+        b = k % NB
         step_no[0] += 1
-        for w in pending[k]:          # the exchange that last used this buffer set must be over before it is overwritten
+        for w in pending[b]:          # the exchange that last used this buffer set must be over before it is overwritten
             w.wait()
-        pending[k] = []
-        chunks, masks = outs[k]
+        pending[b] = []
+        chunks, masks = outs[b]
         if args.no_pipeline:
             dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
         else:
             dec.decode_batch_pipelined(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
-        fresh[k] = True
-        if world > 1 and fresh[k ^ 1]:
-            dec.pipeline_wait(stream.cuda_stream, keep_newest=True)      # step k-1 is complete from here on in stream order
-            gather_of(k ^ 1)
+        fresh[b] = True
+        if world > 1 and k >= D - 1:
+            if not args.no_pipeline:
+                dec.pipeline_wait(stream.cuda_stream, keep_newest=D - 1)   # step k-D+1 is complete from here on in stream order
+            gather_of((k - (D - 1)) % NB)
         return chunks, masks
 
     def drain():
-        # the newest step's outputs (and, with N > 1, its gather) are still outstanding
-        dec.pipeline_wait(stream.cuda_stream, keep_newest=False)
+        # the newest steps' outputs (and, with N > 1, their gathers) are still outstanding
+        if not args.no_pipeline:
+            dec.pipeline_wait(stream.cuda_stream, keep_newest=0)
         if world > 1:
-            gather_of((step_no[0] - 1) & 1)
-        for k in (0, 1):
-            for w in pending[k]:
+            for j in range(max(0, step_no[0] - NB), step_no[0]):
+                gather_of(j % NB)
+        for b in range(NB):
+            for w in pending[b]:
                 w.wait()
-            pending[k] = []
+            pending[b] = []
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -209,7 +214,7 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    all_chunks, all_masks = last[0] if last[0] is not None else outs[(step_no[0] - 1) & 1]
+    all_chunks, all_masks = last[0] if last[0] is not None else outs[(step_no[0] - 1) % NB]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -217,7 +222,7 @@ def main():
 
     # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered, both buffer sets
     ok = True
-    for chunks, masks in outs[:min(2, step_no[0])]:
+    for chunks, masks in outs[:min(NB, step_no[0])]:
         ok = ok and bool((masks == 0xFFF).all().item()) and bool((chunks == payload).all().item())
     if world > 1 and rank == 0:
         ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item()) \
@@ -250,7 +255,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"batch of {n} synthetic clean mode-B frames per GPU, device-resident, bit-exact vs encoded payload",
                        "frames_per_gpu_per_step": n, "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
-                                      ("" if args.no_pipeline else "; steps pipelined: threshold pass of step k+1 overlaps the rest of step k")},
+                                      ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": ALGO_BYTES_PER_FRAME * n,
                          "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,

@@ -75,18 +75,21 @@ int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
 int64_t cimbar_hip_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int rgb_mem, int should_preprocess,
                                 int color_correction, uint8_t* chunks, uint32_t* masks, int out_mem, void* hip_stream);
 
-/* A continuous stream of batches (device buffers only): the same work as cimbar_hip_decode_batch, but only the threshold pass runs on
- * `hip_stream`; the rest of the batch is handed to a stream the context owns, behind the rest of the previous batch (so the colour-
- * correction matrix still carries over from batch to batch in order). The threshold pass of batch k+1 -- the HBM-bound 70 % of the work --
- * then overlaps the latency-bound rest of batch k. The reference's receive loop has the same shape: frames keep arriving while earlier
- * ones are decoded (cimbar_recv_js.cpp:143-189 under web/recv.js's worker pool).
- * Contract: at most two batches are in flight; the rgb / chunks / masks buffers of a batch must stay untouched until a
+/* A continuous stream of batches (device buffers only): the same work and the same results as cimbar_hip_decode_batch, but the call only
+ * records "the frames are ready" on `hip_stream` and runs the batch on one of D = cimbar_hip_pipeline_depth() streams the context owns,
+ * consecutive batches on consecutive streams. Up to D batches are then in flight at once and the threshold pass of one batch -- the
+ * HBM-bound 70 % of the work -- overlaps the short, latency-bound kernels of the others; the colour-correction matrix still carries
+ * over from batch to batch in order (a batch's colour pass waits for the end of the batch before it). The reference's receive loop has
+ * the same shape: frames keep arriving while earlier ones are decoded (cimbar_recv_js.cpp:143-189 under web/recv.js's worker pool).
+ * Contract: at most D batches in flight; the rgb / chunks / masks buffers of a batch must stay untouched until a
  * cimbar_hip_pipeline_wait that covers it has been enqueued and reached. Any other entry point of the context waits for the pipeline.
- *   cimbar_hip_pipeline_wait(ctx, stream, keep_newest): `stream` waits for every pipelined batch issued so far (keep_newest = 0) or for
- *   all but the most recent one (keep_newest = 1: consume batch k-1 while batch k is still being decoded). Enqueue-only, returns 0. */
+ *   cimbar_hip_pipeline_wait(ctx, stream, keep_newest): `stream` waits for every pipelined batch issued so far except the `keep_newest`
+ *   most recent ones (0 = all of them; D-1 = only the oldest that can still be in flight: consume batch k-D+1 right after issuing
+ *   batch k and the pipeline stays full). Enqueue-only, returns 0. */
 int cimbar_hip_decode_batch_pipelined(cimbar_hip_ctx* ctx, const uint8_t* rgb, int n, int should_preprocess, int color_correction,
                                       uint8_t* chunks, uint32_t* masks, void* hip_stream);
 int cimbar_hip_pipeline_wait(cimbar_hip_ctx* ctx, void* hip_stream, int keep_newest);
+int cimbar_hip_pipeline_depth(const cimbar_hip_ctx* ctx);
 
 /* Decoder::decode(img, ostream, should_preprocess, color_correction) (src/lib/encoder/Decoder.h:163-169) -- the `./cimbar --no-fountain`
  * path (cimbar.cpp:270-272) -- for n frames: no aligned_stream, every 125-byte Reed-Solomon output is written where it falls and a

@@ -1770,8 +1770,7 @@ __global__ void k_plane_bytes(const uint32_t* __restrict__ plane, uint8_t* __res
 struct cimbar_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t stream2 = nullptr;            // second half of a batch's tail kernels (see enqueue); pipelined batches: even ones
-	hipStream_t stream3 = nullptr;            // pipelined batches: odd ones
+	hipStream_t stream2 = nullptr;            // second half of a batch's tail kernels (see enqueue)
 	hipEvent_t ev_k1 = nullptr, ev_join = nullptr, ev_mid[8] = {};
 	int tail_split = 1, tail_parts = 2;
 	std::string err;
@@ -1791,17 +1790,20 @@ struct cimbar_hip_ctx {
 	FrameState* d_states = nullptr;
 	float* d_ccm_frames = nullptr;
 	float* d_ccm_used = nullptr;
-	// the pipelined entry point alternates between the scratch above and this second set, so that the threshold pass of batch
-	// k+1 can run while the rest of batch k is still reading its intermediates
-	struct AltScratch {
+	// the pipelined entry point rotates through `pipe_depth` sets of the intermediates above (the members are always the set in
+	// use by the newest batch; the others are parked here) and as many streams, so that several batches are in flight at once
+	static constexpr int MAXP = 4;
+	struct ScratchSet {
 		int cap = 0;
 		uint32_t* d_plane = nullptr; uint32_t* d_cellmean = nullptr; uint8_t* d_symbols = nullptr; uint8_t* d_colors = nullptr;
 		int8_t* d_drift = nullptr; uint32_t* d_flood = nullptr; uint8_t* d_rs_ok = nullptr; FrameState* d_states = nullptr;
 		float* d_ccm_frames = nullptr; float* d_ccm_used = nullptr;
-	} alt;
-	int pipe_set = 0;                 // which set the member pointers above currently are (0 / 1)
-	bool pipe_used[2] = {false, false};
-	hipEvent_t ev_pk1[2] = {}, ev_pdone[2] = {};
+	} parked[MAXP];
+	int pipe_depth = 4;
+	int pipe_set = 0;                 // which set the member pointers above currently are
+	bool pipe_used[MAXP] = {};
+	hipStream_t pstream[MAXP] = {};
+	hipEvent_t ev_pk1[MAXP] = {}, ev_pdone[MAXP] = {};
 	float* d_carry = nullptr;         // 10 floats
 	uint8_t* d_template = nullptr;    // encode half: empty frame (background, anchors, guides)
 	uint8_t* d_gen_log = nullptr;     // encode half: logs of the 30 low generator coefficients
@@ -2001,32 +2003,39 @@ void destroy_ctx(cimbar_hip_ctx* ctx)
 	for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-	if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+	for (int k = 2; k < cimbar_hip_ctx::MAXP; ++k) if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]);
 	for (hipEvent_t e : {ctx->ev_k1, ctx->ev_join}) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->ev_mid) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->ev_pk1) if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->ev_pdone) if (e) (void)hipEventDestroy(e);
-	fr(ctx->alt.d_plane); fr(ctx->alt.d_cellmean); fr(ctx->alt.d_symbols); fr(ctx->alt.d_colors); fr(ctx->alt.d_drift); fr(ctx->alt.d_flood);
-	fr(ctx->alt.d_rs_ok); fr(ctx->alt.d_states); fr(ctx->alt.d_ccm_frames); fr(ctx->alt.d_ccm_used);
+	for (auto& a : ctx->parked) {
+		fr(a.d_plane); fr(a.d_cellmean); fr(a.d_symbols); fr(a.d_colors); fr(a.d_drift); fr(a.d_flood);
+		fr(a.d_rs_ok); fr(a.d_states); fr(a.d_ccm_frames); fr(a.d_ccm_used);
+	}
 	delete ctx;
 }
 
 // pipelined batches in flight use the scratch sets and the tail stream: anything else that touches them on `st` waits first
 int drain_pipeline_into(cimbar_hip_ctx* ctx, hipStream_t st)
 {
-	for (int k = 0; k < 2; ++k)
+	for (int k = 0; k < cimbar_hip_ctx::MAXP; ++k)
 		if (ctx->pipe_used[k]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[k], 0));   // (a completed event costs nothing to wait for)
 	return 0;
 }
 
-void swap_scratch_sets(cimbar_hip_ctx* ctx)
+// park the set in use, take the next one (each set is owned by exactly one of: the members, one parked[] slot)
+void rotate_scratch_sets(cimbar_hip_ctx* ctx)
 {
-	std::swap(ctx->cap, ctx->alt.cap);
-	std::swap(ctx->d_plane, ctx->alt.d_plane); std::swap(ctx->d_cellmean, ctx->alt.d_cellmean); std::swap(ctx->d_symbols, ctx->alt.d_symbols);
-	std::swap(ctx->d_colors, ctx->alt.d_colors); std::swap(ctx->d_drift, ctx->alt.d_drift); std::swap(ctx->d_flood, ctx->alt.d_flood);
-	std::swap(ctx->d_rs_ok, ctx->alt.d_rs_ok); std::swap(ctx->d_states, ctx->alt.d_states); std::swap(ctx->d_ccm_frames, ctx->alt.d_ccm_frames);
-	std::swap(ctx->d_ccm_used, ctx->alt.d_ccm_used);
-	ctx->pipe_set ^= 1;
+	auto exchange = [&](cimbar_hip_ctx::ScratchSet& a) {
+		std::swap(ctx->cap, a.cap);
+		std::swap(ctx->d_plane, a.d_plane); std::swap(ctx->d_cellmean, a.d_cellmean); std::swap(ctx->d_symbols, a.d_symbols);
+		std::swap(ctx->d_colors, a.d_colors); std::swap(ctx->d_drift, a.d_drift); std::swap(ctx->d_flood, a.d_flood);
+		std::swap(ctx->d_rs_ok, a.d_rs_ok); std::swap(ctx->d_states, a.d_states); std::swap(ctx->d_ccm_frames, a.d_ccm_frames);
+		std::swap(ctx->d_ccm_used, a.d_ccm_used);
+	};
+	exchange(ctx->parked[ctx->pipe_set]);                       // members (set pipe_set) -> its slot; members now empty
+	ctx->pipe_set = (ctx->pipe_set + 1) % ctx->pipe_depth;
+	exchange(ctx->parked[ctx->pipe_set]);                       // slot of the next set -> members; that slot now empty
 }
 
 // enqueue the whole pipeline for n device-resident frames on stream `st`
@@ -2059,8 +2068,8 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 			if (hipError_t e = (s == st ? mark() : hipSuccess)) return e;
 			{
 				// the two halves of a split batch may run their flood kernels at the same time: each gets its own half of the spill areas
-				const int areas = (split || pipe) ? FLOOD_GRID / 2 : FLOOD_GRID;
-				const int area0 = ((split && s != st) || (pipe && ctx->pipe_set)) ? FLOOD_GRID / 2 : 0;
+				const int areas = pipe ? FLOOD_GRID / ctx->pipe_depth : (split ? FLOOD_GRID / 2 : FLOOD_GRID);
+				const int area0 = pipe ? ctx->pipe_set * areas : ((split && s != st) ? FLOOD_GRID / 2 : 0);
 				hipLaunchKernelGGL(k_flood, dim3(m < areas ? m : areas), dim3(64), 0, s, ctx->d_plane, ctx->tb, ctx->flood, ctx->d_flood, ctx->d_symbols,
 				                   ctx->d_drift, fa, m, area0);
 			}
@@ -2080,12 +2089,12 @@ int enqueue(cimbar_hip_ctx* ctx, hipStream_t st, const uint8_t* d_rgb, int n, in
 		return s == st ? mark() : hipSuccess;
 	};
 	if (pipe) {
-		// the whole batch runs on one of the context's two streams (`st` here), the next batch on the other one: two independent
-		// queues, so K1 of one batch overlaps the short kernels of the other. The one thing that crosses over is the colour-
+		// the whole batch runs on one of the context's pipeline streams (`st` here), the next batch on the next one: independent
+		// queues, so K1 of one batch overlaps the short kernels of the others. The one thing that crosses over is the colour-
 		// correction carry (and the order of the results): this batch's colour pass waits for the previous batch's end.
-		const int set = ctx->pipe_set;
+		const int set = ctx->pipe_set, prev = (set + ctx->pipe_depth - 1) % ctx->pipe_depth;
 		HIPCHK(tail(st, f0, n, 0));
-		if (ctx->pipe_used[set ^ 1]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[set ^ 1], 0));
+		if (ctx->pipe_used[prev]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[prev], 0));
 		HIPCHK(tail(st, f0, n, 1));
 		HIPCHK(hipEventRecord(ctx->ev_pdone[set], st));
 		ctx->pipe_used[set] = true;
@@ -2142,7 +2151,15 @@ int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out)
 	auto fail = [&](int code) { destroy_ctx(ctx); return code; };
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
-	if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
+	if (const char* v = std::getenv("CIMBAR_HIP_PIPE_DEPTH")) { int k = std::atoi(v); if (k >= 2 && k <= cimbar_hip_ctx::MAXP) ctx->pipe_depth = k; }
+	// As few streams as possible: the runtime multiplexes streams onto (by default) four hardware queues, and how the pipeline's
+	// streams fall onto them matters (measured, 1024-frame batches: depth 4 over six streams 0.81 ms per batch, slower than depth 2;
+	// depth 4 over these four streams 0.68 ms; raising GPU_MAX_HW_QUEUES to 8 made it worse again). So the pipeline reuses the two
+	// streams the context has anyway and adds only what the depth needs beyond them.
+	ctx->pstream[0] = ctx->stream;
+	ctx->pstream[1] = ctx->stream2;
+	for (int k = 2; k < ctx->pipe_depth; ++k)
+		if (hipStreamCreateWithFlags(&ctx->pstream[k], hipStreamNonBlocking) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	for (hipEvent_t* e : {&ctx->ev_k1, &ctx->ev_join})
 		if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
 	for (hipEvent_t& e : ctx->ev_mid) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(CIMBAR_HIP_EHIP);
@@ -2166,7 +2183,7 @@ int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx)
 {
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	HIPCHK(hipSetDevice(ctx->device));
-	if (ctx->pipe_used[0] || ctx->pipe_used[1]) HIPCHK(hipDeviceSynchronize());   // pipelined batches still carry the matrix forward
+	HIPCHK(hipDeviceSynchronize());   // pipelined batches in flight still carry the matrix forward
 	HIPCHK(hipMemsetAsync(ctx->d_carry, 0, sizeof(float) * 10, ctx->stream));
 	HIPCHK(hipStreamSynchronize(ctx->stream));
 	return 0;
@@ -2231,25 +2248,29 @@ int cimbar_hip_decode_batch_pipelined(cimbar_hip_ctx* ctx, const uint8_t* rgb, i
 	if (!rgb || !chunks || !masks || n <= 0) { ctx->err = "decode_batch_pipelined: null buffer or n <= 0"; return CIMBAR_HIP_EINVAL; }
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t st = (hipStream_t)hip_stream;
-	swap_scratch_sets(ctx);
+	rotate_scratch_sets(ctx);
 	const int set = ctx->pipe_set;
-	hipStream_t own = set ? ctx->stream3 : ctx->stream2;
+	hipStream_t own = ctx->pstream[set];
 	// the frames are whatever `hip_stream` has produced up to here
 	HIPCHK(hipEventRecord(ctx->ev_pk1[set], st));
 	HIPCHK(hipStreamWaitEvent(own, ctx->ev_pk1[set], 0));
-	// (this set's intermediates belong to the batch issued two calls ago on the same stream: stream order keeps them apart)
+	// (this set's intermediates belong to the batch issued pipe_depth calls ago on the same stream: stream order keeps them apart)
 	if (int r = ensure_capacity(ctx, n)) return r;
 	return enqueue(ctx, own, rgb, n, should_preprocess, color_correction, chunks, masks, 0, true);
 }
+
+int cimbar_hip_pipeline_depth(const cimbar_hip_ctx* ctx) { return ctx ? ctx->pipe_depth : CIMBAR_HIP_EINVAL; }
 
 int cimbar_hip_pipeline_wait(cimbar_hip_ctx* ctx, void* hip_stream, int keep_newest)
 {
 	if (!ctx) return CIMBAR_HIP_EINVAL;
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t st = (hipStream_t)hip_stream;
-	const int newest = ctx->pipe_set, older = newest ^ 1;
-	if (ctx->pipe_used[older]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[older], 0));
-	if (!keep_newest && ctx->pipe_used[newest]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[newest], 0));
+	// batch j's colour pass waits for batch j-1's end, so the end of one batch implies the end of every earlier one
+	if (keep_newest < 0) keep_newest = 0;
+	if (keep_newest >= ctx->pipe_depth) return 0;
+	const int target = (ctx->pipe_set + ctx->pipe_depth - keep_newest) % ctx->pipe_depth;
+	if (ctx->pipe_used[target]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_pdone[target], 0));
 	return 0;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = (
     "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
-    "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait",
+    "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
 )
 
 
@@ -64,6 +64,8 @@ def load_library(path=None):
     lib.cimbar_hip_decode_batch_pipelined.restype = i32
     lib.cimbar_hip_pipeline_wait.argtypes = [vp, vp, i32]
     lib.cimbar_hip_pipeline_wait.restype = i32
+    lib.cimbar_hip_pipeline_depth.argtypes = [vp]
+    lib.cimbar_hip_pipeline_depth.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -170,16 +172,21 @@ class HipDecoder:
 
     def decode_batch_pipelined(self, frames_ptr, n, chunks_ptr, masks_ptr, should_preprocess=False, color_correction=2, stream=None):
         """Like decode_batch_device, but only the threshold pass runs on `stream`: the rest of the batch overlaps the next batch's
-        threshold pass. Outputs are valid once a later pipeline_wait() on a stream has been reached; at most two batches in flight."""
+        threshold pass. Outputs are valid once a later pipeline_wait() on a stream has been reached; at most pipeline_depth batches in
+        flight."""
         rc = self._lib.cimbar_hip_decode_batch_pipelined(self._ctx, ctypes.c_void_p(frames_ptr), int(n), int(bool(should_preprocess)),
                                                          int(color_correction), ctypes.c_void_p(chunks_ptr), ctypes.c_void_p(masks_ptr),
                                                          ctypes.c_void_p(stream) if stream else None)
         self._check(rc, "cimbar_hip_decode_batch_pipelined")
 
-    def pipeline_wait(self, stream=None, keep_newest=False):
-        """`stream` waits for the pipelined batches issued so far (all but the newest one with keep_newest)."""
-        self._check(self._lib.cimbar_hip_pipeline_wait(self._ctx, ctypes.c_void_p(stream) if stream else None, int(bool(keep_newest))),
+    def pipeline_wait(self, stream=None, keep_newest=0):
+        """`stream` waits for the pipelined batches issued so far except the `keep_newest` most recent ones."""
+        self._check(self._lib.cimbar_hip_pipeline_wait(self._ctx, ctypes.c_void_p(stream) if stream else None, int(keep_newest)),
                     "cimbar_hip_pipeline_wait")
+
+    @property
+    def pipeline_depth(self):
+        return int(self._lib.cimbar_hip_pipeline_depth(self._ctx))
 
     # ------------------------------------------------------------------ the reference's operator surface
     def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):

@@ -68,3 +68,39 @@ def test_pipelined_then_ordinary_calls_mix(synth):
         assert bool((m[k] == 0xFFF).all()) and (c[k].cpu().numpy() == payload).all()
     total, chunks, masks = dec.decode_batch(clean)   # host entry point after pipelined use
     assert total == 15000 and (chunks.reshape(2, -1) == payload).all()
+
+
+def test_pipeline_keeps_order_over_many_batches(synth):
+    """more batches than the pipeline is deep, consumed D-1 steps behind: every scratch set and stream is reused several times"""
+    dev = torch.device("cuda", 0)
+    payload, clean = F.clean_frames(synth, 4, seed=21)
+    variants = [np.ascontiguousarray(np.stack([clean[k], F.add_noise(clean[(k + 1) % 4], 35 + 10 * k, k), F.shift(clean[(k + 2) % 4], k - 1, 1)]))
+                for k in range(4)]
+    tens = [torch.from_numpy(v).to(dev) for v in variants]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    nb = 11
+    ref_dec = D.HipDecoder(0)
+    want = []
+    for k in range(nb):
+        want.append(ref_dec.decode_batch(variants[k % 4]))
+    ref_dec.close()
+
+    dec = D.HipDecoder(0)
+    depth = dec.pipeline_depth
+    assert 2 <= depth <= 4
+    outs = [(torch.zeros((3, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((3,), dtype=torch.int32, device=dev)) for _ in range(nb)]
+    got = [None] * nb
+    for k in range(nb):
+        c, m = outs[k]
+        dec.decode_batch_pipelined(tens[k % 4].data_ptr(), 3, c.data_ptr(), m.data_ptr(), False, 2, st)
+        j = k - (depth - 1)
+        if j >= 0:
+            dec.pipeline_wait(st, keep_newest=depth - 1)
+            got[j] = (outs[j][0].clone(), outs[j][1].clone())      # stream-ordered copies: must already see batch j's results
+    dec.pipeline_wait(st)
+    torch.cuda.synchronize()
+    for j in range(nb):
+        c, m = got[j] if got[j] is not None else outs[j]
+        assert (m.cpu().numpy().astype(np.uint32) == want[j][2]).all(), j
+        assert (c.cpu().numpy().reshape(3, 12, 625) == want[j][1]).all(), j
+    dec.close()
