@@ -133,6 +133,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the decoder's streams are created first, right behind the null stream: how streams fall onto the runtime's hardware queues
+    # depends on creation order, and this is the order the pipeline was measured in (DESIGN.md "Launch structure")
+    dec = HipDecoder(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -140,7 +143,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.frames
-    dec = HipDecoder(local_rank)
     payload, frames = make_frames(n, dev, seed=1234 + rank, dec=dec)
     # The batches form a continuous stream, so the library's pipelined entry point is used: up to D = pipeline_depth steps are in flight
     # on the context's own streams, the threshold pass of one overlapping the short kernels of the others (colour-correction carry-over
