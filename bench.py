@@ -154,50 +154,21 @@ def main():
             for _ in range(NB)]
     gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev),
                  torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(NB)]
-    pending = [[] for _ in range(NB)]
-    fresh = [False] * NB              # buffer set b holds a decoded step that has not been gathered yet
     stream = torch.cuda.current_stream(dev)
-    step_no = [0]
-    last = [None]
 
-    def gather_of(b):
-        if not fresh[b]:
-            return
-        fresh[b] = False
-        chunks, masks = outs[b]
-        all_c, all_m, pending[b] = multigpu.gather_chunks(chunks, masks, dst=0, out=gathered[b], async_op=True)
-        last[0] = (all_c, all_m)
-
-    def step():
-        k = step_no[0]
-        b = k % NB
-        step_no[0] += 1
-        for w in pending[b]:          # the exchange that last used this buffer set must be over before it is overwritten
-            w.wait()
-        pending[b] = []
+    def issue(b, k):
         chunks, masks = outs[b]
         if args.no_pipeline:
             dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
         else:
             dec.decode_batch_pipelined(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
-        fresh[b] = True
-        if world > 1 and k >= D - 1:
-            if not args.no_pipeline:
-                dec.pipeline_wait(stream.cuda_stream, keep_newest=D - 1)   # step k-D+1 is complete from here on in stream order
-            gather_of((k - (D - 1)) % NB)
-        return chunks, masks
 
-    def drain():
-        # the newest steps' outputs (and, with N > 1, their gathers) are still outstanding
+    def ready(keep_newest):
         if not args.no_pipeline:
-            dec.pipeline_wait(stream.cuda_stream, keep_newest=0)
-        if world > 1:
-            for j in range(max(0, step_no[0] - NB), step_no[0]):
-                gather_of(j % NB)
-        for b in range(NB):
-            for w in pending[b]:
-                w.wait()
-            pending[b] = []
+            dec.pipeline_wait(stream.cuda_stream, keep_newest=keep_newest)
+
+    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered, dst=0)
+    step, drain = pipe.step, pipe.drain
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -216,7 +187,7 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    all_chunks, all_masks = last[0] if last[0] is not None else outs[(step_no[0] - 1) % NB]
+    all_chunks, all_masks = pipe.last if pipe.last is not None else outs[(pipe.steps - 1) % NB]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,7 +195,7 @@ def main():
 
     # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered, both buffer sets
     ok = True
-    for chunks, masks in outs[:min(NB, step_no[0])]:
+    for chunks, masks in outs[:min(NB, pipe.steps)]:
         ok = ok and bool((masks == 0xFFF).all().item()) and bool((chunks == payload).all().item())
     if world > 1 and rank == 0:
         ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item()) \

@@ -45,6 +45,67 @@ def gather_chunks(chunks, masks, dst=0, group=None, out=None, async_op=False):
     return (all_c, all_m, works) if async_op else (all_c, all_m)
 
 
+class StepPipeline:
+    """Host-side bookkeeping for a continuous stream of decode steps on one rank (what bench.py's timed loop is):
+
+      * `depth` steps may be in flight (HipDecoder.decode_batch_pipelined); step k writes output buffer set k % nbuf;
+      * with world > 1 the outputs of step k-(depth-1) are gathered to rank 0 right after step k has been issued (RCCL runs the
+        exchange on its own stream), so neither the decode pipeline nor the exchange ever waits for the other;
+      * a buffer set is not handed to a new step before the exchange that last read it is over.
+
+    issue(buf, step) enqueues one decode into outs[buf]; ready(keep_newest) makes the current stream wait for every issued step
+    except the `keep_newest` most recent ones. Both are callables so that the CPU test can drive the same logic with gloo."""
+
+    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None):
+        self.outs, self.depth, self.issue, self.ready = outs, max(1, int(depth)), issue, ready
+        self.nbuf = len(outs)
+        assert self.nbuf >= self.depth, "one output buffer set per step in flight"
+        self.gathered = gathered if gathered is not None else [None] * self.nbuf
+        self.dst, self.group = dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pending = [[] for _ in range(self.nbuf)]
+        self.fresh = [False] * self.nbuf
+        self.steps = 0
+        self.last = None               # (all_chunks, all_masks) of the most recent gather (rank `dst` only)
+        self.gathers = 0
+
+    def _gather(self, b):
+        if not self.fresh[b]:
+            return
+        self.fresh[b] = False
+        chunks, masks = self.outs[b]
+        all_c, all_m, self.pending[b] = gather_chunks(chunks, masks, dst=self.dst, group=self.group, out=self.gathered[b], async_op=True)
+        self.last = (all_c, all_m)
+        self.gathers += 1
+
+    def step(self):
+        k = self.steps
+        b = k % self.nbuf
+        self.steps += 1
+        for w in self.pending[b]:      # the exchange that last used this buffer set must be over before it is overwritten
+            if w is not None:
+                w.wait()
+        self.pending[b] = []
+        self.issue(b, k)
+        self.fresh[b] = True
+        if self.world > 1 and k >= self.depth - 1:
+            self.ready(self.depth - 1)                     # step k-depth+1 is complete from here on in stream order
+            self._gather((k - (self.depth - 1)) % self.nbuf)
+        return self.outs[b]
+
+    def drain(self):
+        """everything issued so far is complete (and gathered) once the current stream has reached this point"""
+        self.ready(0)
+        if self.world > 1:
+            for j in range(max(0, self.steps - self.nbuf), self.steps):
+                self._gather(j % self.nbuf)
+        for b in range(self.nbuf):
+            for w in self.pending[b]:
+                if w is not None:
+                    w.wait()
+            self.pending[b] = []
+
+
 def feed_sink(sink_decode_frame, chunks, masks, on_complete=None):
     """Rank-0 side: hand every delivered chunk to fountain_decoder_sink::decode_frame (fountain_decoder_sink.h:133-166) in
     frame order then chunk order -- exactly the order a single-threaded reference decoder would have produced.

@@ -93,3 +93,59 @@ def test_fountain_stream_reassembles_through_single_sink(tmp_path, ref):
 def test_shard_range():
     assert [multigpu.shard_range(10, r, 4)[:2] for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert multigpu.shard_range(8192, 7, 8)[:2] == (7168, 8192)
+
+
+def _pipeline_worker(rank, world, port, depth, nsteps, result_path):
+    """bench.py's timed loop in miniature: `depth` steps in flight, each step's outputs gathered depth-1 steps later"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3
+        nbuf = max(depth, 2)
+        outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8), torch.zeros((n,), dtype=torch.int32)) for _ in range(nbuf)]
+        gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8), torch.zeros((world * n,), dtype=torch.int32))
+                    if rank == 0 else None for _ in range(nbuf)]
+        issued, waits, seen = [], [], []
+
+        def issue(b, k):           # stand-in for decode_batch_pipelined: the "decoded" bytes name the step and the rank
+            outs[b][0].fill_((k * 7 + rank) % 251)
+            outs[b][1].fill_(k * 100 + rank)
+            issued.append((b, k))
+
+        def ready(keep_newest):
+            waits.append(keep_newest)
+
+        pipe = multigpu.StepPipeline(outs, depth, issue, ready, gathered=gathered, dst=0)
+        orig_gather = pipe._gather
+
+        def spy(b):
+            before = pipe.gathers
+            orig_gather(b)
+            if pipe.gathers > before and rank == 0:
+                for w in pipe.pending[b]:
+                    w.wait()
+                seen.append((int(pipe.last[1][0]) // 100, pipe.last[0][:, 0].clone(), pipe.last[1].clone()))
+        pipe._gather = spy
+        for _ in range(nsteps):
+            pipe.step()
+        pipe.drain()
+        assert pipe.gathers == nsteps, "every step is gathered exactly once"
+        assert [k for _, k in issued] == list(range(nsteps))
+        assert waits[-1] == 0 and all(w == depth - 1 for w in waits[:-1])
+        if rank == 0:
+            assert [s for s, _, _ in seen] == list(range(nsteps)), "steps reach rank 0 in order"
+            for s, c0, m in seen:
+                want_m = torch.tensor([s * 100 + r for r in range(world) for _ in range(n)], dtype=torch.int32)
+                want_c = torch.tensor([(s * 7 + r) % 251 for r in range(world) for _ in range(n)], dtype=torch.uint8)
+                assert (m == want_m).all() and (c0 == want_c).all(), s
+            open(result_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,nsteps", [(4, 11), (2, 5), (1, 3), (4, 2)])
+def test_step_pipeline_gathers_every_step_once_and_in_order(tmp_path, depth, nsteps):
+    res = tmp_path / "ok"
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), depth, nsteps, str(res)), nprocs=2, join=True)
+    assert res.read_text() == "ok"
