@@ -15,19 +15,21 @@ from oracle.pyref import P
 pytestmark = pytest.mark.gpu
 
 
-def test_fountain_stream_through_sharded_decode_and_single_sink(hip_decoder, ref):
+@pytest.mark.parametrize("size,n_frames", [(1 << 20, 160), (16 << 20, 8192)], ids=["1MiB-160frames", "config4-16MiB-8192frames"])
+def test_fountain_stream_through_sharded_decode_and_single_sink(hip_decoder, ref, size, n_frames):
+    """the second case is BASELINE configs[3] at full size (16 MiB file, 8192 frames = 98 304 chunks whose 16-bit block ids wrap after
+    frame 5461, eight slabs of 1024 frames), the eight ranks played one after the other by the one GPU of the test box"""
     dev = torch.device("cuda", 0)
-    data = np.random.default_rng(4321).integers(0, 256, 1 << 20, dtype=np.uint8)       # 1 MiB file -> 1695 wirehair blocks
-    n_frames, world = 160, 8
+    data = np.random.default_rng(4321).integers(0, 256, size, dtype=np.uint8)       # 1 MiB file -> 1695 wirehair blocks
+    world = 8
     chunks_in = np.zeros((n_frames * 12, 625), np.uint8)
     assert ref.ref_fountain_chunks(P(data), data.size, 9, n_frames * 12, P(chunks_in)) == n_frames * 12
     payload = torch.from_numpy(chunks_in.reshape(n_frames, 7500)).to(dev)
-    synth = framegen.FrameSynth(dev)
-
     outs, masks_all = [], []
     for rank in range(world):                                   # what rank `rank` of an 8-GPU job would do
         lo, hi, per = multigpu.shard_range(n_frames, rank, world)
-        frames = synth.frames_from_payload(payload[lo:hi])
+        frames = torch.empty((hi - lo, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+        hip_decoder.encode_batch_device(payload[lo:hi].contiguous().data_ptr(), hi - lo, frames.data_ptr(), torch.cuda.current_stream().cuda_stream)
         c = torch.zeros((per, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
         m = torch.zeros((per,), dtype=torch.int32, device=dev)
         dec = hip_decoder
@@ -36,6 +38,7 @@ def test_fountain_stream_through_sharded_decode_and_single_sink(hip_decoder, ref
         torch.cuda.synchronize()
         outs.append(c)
         masks_all.append(m)
+        del frames
     all_chunks, all_masks = torch.cat(outs, 0), torch.cat(masks_all, 0)     # == gather to rank 0 in rank order
     assert bool((all_chunks[:n_frames] == payload).all())
 
