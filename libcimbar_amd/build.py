@@ -23,11 +23,17 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the cimbar HIP library cannot be built (there is no CPU fallback)")
 
 
+def sources():
+    """the translation unit, the sections it includes (csrc/*.hip.inc) and the public header"""
+    d = os.path.dirname(SRC)
+    return [SRC, HEADER] + sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".hip.inc"))
+
+
 def needs_build(out=OUT):
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    return any(os.path.getmtime(p) > t for p in (SRC, HEADER))
+    return any(os.path.getmtime(p) > t for p in sources())
 
 
 def build_hip(force=False, verbose=False, out=OUT, defines=()):

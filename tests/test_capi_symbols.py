@@ -42,7 +42,7 @@ def test_product_never_touches_the_oracle():
     for base in ("libcimbar_amd", "include"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for fn in files:
-                if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                if fn.endswith((".py", ".hip", ".inc", ".h", ".hpp", ".cpp")):
                     text = open(os.path.join(dirpath, fn), errors="replace").read()
                     for pat in pats:
                         assert not re.search(pat, text, flags=re.M), (fn, pat)
