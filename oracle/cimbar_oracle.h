@@ -73,6 +73,17 @@ const uint8_t* co_last_symbols(void);   /* CO_CELLS bytes, by cell index */
 const uint8_t* co_last_colors(void);    /* CO_CELLS bytes, by cell index */
 const int32_t* co_last_positions(void); /* 2*CO_CELLS, drifted x,y by cell index */
 
+/* ---- the stage in front of the decoder (oracle/cimbar_oracle_extract.c). Parity unpinned at the OpenCV boundary. */
+/* Scanner::preprocess_image(img, fast=true), Scanner.h:148-165: gray -> 3x3|5x5 Gaussian -> Otsu. out: w*h bytes 0/255. Returns the threshold. */
+int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out);
+/* cv::getPerspectiveTransform as called by Deskewer::deskew, Deskewer.h:36. Row-major 3x3 into m9. */
+int co_perspective_transform(const float* src8, const float* dst8, double* m9);
+void co_deskew_points(float* dst8);
+/* cv::warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0), Deskewer.h:38: RGB8 sw x sh -> RGB8 width x height */
+int co_warp_perspective(const uint8_t* rgb, int sw, int sh, const double* m9, uint8_t* out, int width, int height);
+/* Deskewer::deskew for mode B from the four corners (top-left, top-right, bottom-left, bottom-right; x, y) */
+int co_deskew(const uint8_t* rgb, int sw, int sh, const float* corners8, uint8_t* out1024);
+
 #ifdef __cplusplus
 }
 #endif

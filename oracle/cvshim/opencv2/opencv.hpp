@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <array>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -37,6 +38,7 @@ typedef unsigned char uchar;
 #define CV_VERSION_MAJOR 4
 #define CV_8U 0
 #define CV_32F 5
+#define CV_64F 6
 #define CV_CN_SHIFT 3
 #define CV_MAT_DEPTH(t) ((t) & 7)
 #define CV_MAT_CN(t) ((((t) >> CV_CN_SHIFT) & 63) + 1)
@@ -45,12 +47,14 @@ typedef unsigned char uchar;
 #define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_8UC4 CV_MAKETYPE(CV_8U, 4)
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
 
 namespace cv {
 
 enum { COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4, COLOR_RGBA2RGB = 1, COLOR_RGB2GRAY = 7 };
 enum { ADAPTIVE_THRESH_MEAN_C = 0 };
-enum { THRESH_BINARY = 0 };
+enum { THRESH_BINARY = 0, THRESH_OTSU = 8 };
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
 enum { DECOMP_LU = 0, DECOMP_SVD = 1 };
 enum AccessFlag { ACCESS_READ = 1 << 24, ACCESS_RW = 3 << 24 };
 
@@ -60,6 +64,7 @@ static inline uchar saturate_u8(int v) { return (uchar)(v < 0 ? 0 : (v > 255 ? 2
 
 struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} };
 struct Point { int x = 0, y = 0; Point() {} Point(int x_, int y_) : x(x_), y(y_) {} };
+struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
 struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
 
 struct Scalar
@@ -198,7 +203,8 @@ public:
 	int type() const { return _type; }
 	int depth() const { return CV_MAT_DEPTH(_type); }
 	int channels() const { return CV_MAT_CN(_type); }
-	size_t elemSize() const { return (size_t)channels() * (depth() == CV_32F ? 4 : 1); }
+	size_t elemSize() const { return (size_t)channels() * (depth() == CV_64F ? 8 : (depth() == CV_32F ? 4 : 1)); }
+	Size size() const { return Size(cols, rows); }
 	bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
 	bool isContinuous() const { return step == (size_t)cols * elemSize() || rows <= 1; }
 	size_t total() const { return (size_t)rows * cols; }
@@ -615,6 +621,194 @@ inline double invert(const Mat& src_, Mat& dst, int method)
 	}
 	dst = out;
 	return W[0] >= FLT_EPSILON ? W[n - 1] / W[0] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------- extractor (Scanner / Deskewer)
+// [assumed-OpenCV] smooth.dispatch.cpp GaussianBlur for CV_8U, sigma <= 0, ksize 3 | 5: the small fixed kernels [1 2 1]/4 and
+// [1 4 6 4 1]/16 (getGaussianKernel's small_gaussian_tab), run by the fixed-point path (ufixedpoint16 8.8 weights, horizontal
+// pass in 16 bit, vertical pass in 32 bit, one final rounding): dst = (sum_ij w_i w_j p + 2^(s-1)) >> s with integer weights
+// summing to 2^s (s = 4 | 8). BORDER_DEFAULT = BORDER_REFLECT_101.
+inline void GaussianBlur(const Mat& src_, Mat& dst, Size ksize, double, double = 0)
+{
+	if (src_.type() != CV_8UC1 || ksize.width != ksize.height || (ksize.width != 3 && ksize.width != 5))
+	{ std::cerr << "cv-shim: GaussianBlur: CV_8UC1 with ksize 3 or 5 only" << std::endl; std::abort(); }
+	Mat src = src_.clone();
+	const int W = src.cols, H = src.rows, r = ksize.width / 2;
+	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1};
+	const int* k = r == 1 ? k3 : k5;
+	const int shift = r == 1 ? 4 : 8;
+	auto refl = [](int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; };
+	std::vector<int> h((size_t)W * H);
+	for (int y = 0; y < H; ++y)
+	{
+		const uchar* s = src.ptr<uchar>(y);
+		for (int x = 0; x < W; ++x)
+		{
+			int acc = 0;
+			for (int t = -r; t <= r; ++t) acc += k[t + r] * s[refl(x + t, W)];
+			h[(size_t)y * W + x] = acc;
+		}
+	}
+	Mat out(H, W, CV_8UC1);
+	for (int y = 0; y < H; ++y)
+		for (int x = 0; x < W; ++x)
+		{
+			int acc = 0;
+			for (int t = -r; t <= r; ++t) acc += k[t + r] * h[(size_t)refl(y + t, H) * W + x];
+			out.ptr<uchar>(y)[x] = (uchar)((acc + (1 << (shift - 1))) >> shift);
+		}
+	dst = out;
+}
+
+// [assumed-OpenCV] thresh.cpp threshold(THRESH_BINARY | THRESH_OTSU) for CV_8UC1: getThreshVal_Otsu_8u, then dst = src > t ? maxval : 0
+inline double threshold(const Mat& src_, Mat& dst, double thresh, double maxval, int type)
+{
+	if (src_.type() != CV_8UC1) { std::cerr << "cv-shim: threshold: CV_8UC1 only" << std::endl; std::abort(); }
+	Mat src = src_.clone();
+	const int W = src.cols, H = src.rows;
+	if (type & THRESH_OTSU)
+	{
+		int hist[256] = {0};
+		for (int y = 0; y < H; ++y) { const uchar* s = src.ptr<uchar>(y); for (int x = 0; x < W; ++x) hist[s[x]]++; }
+		double mu = 0, scale = 1. / ((double)W * H);
+		for (int i = 0; i < 256; ++i) mu += i * (double)hist[i];
+		mu *= scale;
+		double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+		for (int i = 0; i < 256; ++i)
+		{
+			double p_i, q2, mu2, sigma;
+			p_i = hist[i] * scale;
+			mu1 *= q1;
+			q1 += p_i;
+			q2 = 1. - q1;
+			if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+			mu1 = (mu1 + i * p_i) / q1;
+			mu2 = (mu - q1 * mu1) / q2;
+			sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+			if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+		}
+		thresh = max_val;
+	}
+	const int t = cvFloor(thresh);
+	const uchar on = saturate_u8(cvRound(maxval));
+	Mat out(H, W, CV_8UC1);
+	for (int y = 0; y < H; ++y) { const uchar* s = src.ptr<uchar>(y); uchar* o = out.ptr<uchar>(y); for (int x = 0; x < W; ++x) o[x] = s[x] > t ? on : 0; }
+	dst = out;
+	return thresh;
+}
+
+namespace shim_detail {
+// [assumed-OpenCV] hal LU (matrix_decomp.cpp LUImpl<double>): partial pivoting, eliminate with d = -1/pivot, back-substitute
+inline int lu_solve(double* A, int m, double* b)
+{
+	const double eps = DBL_EPSILON * 100;
+	for (int i = 0; i < m; ++i)
+	{
+		int k = i;
+		for (int j = i + 1; j < m; ++j) if (std::abs(A[j * m + i]) > std::abs(A[k * m + i])) k = j;
+		if (std::abs(A[k * m + i]) < eps) return 0;
+		if (k != i) { for (int j = i; j < m; ++j) std::swap(A[i * m + j], A[k * m + j]); std::swap(b[i], b[k]); }
+		double d = -1 / A[i * m + i];
+		for (int j = i + 1; j < m; ++j)
+		{
+			double alpha = A[j * m + i] * d;
+			for (int c = i + 1; c < m; ++c) A[j * m + c] += alpha * A[i * m + c];
+			b[j] += alpha * b[i];
+		}
+	}
+	for (int i = m - 1; i >= 0; --i)
+	{
+		double s = b[i];
+		for (int c = i + 1; c < m; ++c) s -= A[i * m + c] * b[c];
+		b[i] = s / A[i * m + i];
+	}
+	return 1;
+}
+// [assumed-OpenCV] lapack.cpp invert() closed form for 3x3 CV_64F (det3, then the adjugate times 1/det)
+inline bool invert3x3(const double* S, double* t)
+{
+	double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+	if (d == 0.) return false;
+	d = 1. / d;
+	t[0] = (S[4] * S[8] - S[5] * S[7]) * d; t[1] = (S[2] * S[7] - S[1] * S[8]) * d; t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+	t[3] = (S[5] * S[6] - S[3] * S[8]) * d; t[4] = (S[0] * S[8] - S[2] * S[6]) * d; t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+	t[6] = (S[3] * S[7] - S[4] * S[6]) * d; t[7] = (S[1] * S[6] - S[0] * S[7]) * d; t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+	return true;
+}
+}  // namespace shim_detail
+
+// [assumed-OpenCV] imgwarp.cpp getPerspectiveTransform(src[4], dst[4]): 8x8 system, solve(DECOMP_LU), M[8] = 1
+inline Mat getPerspectiveTransform(const std::vector<Point2f>& src, const std::vector<Point2f>& dst, int = DECOMP_LU)
+{
+	double a[8][8], b[8];
+	for (int i = 0; i < 4; ++i)
+	{
+		a[i][0] = a[i + 4][3] = src[i].x;
+		a[i][1] = a[i + 4][4] = src[i].y;
+		a[i][2] = a[i + 4][5] = 1;
+		a[i][3] = a[i][4] = a[i][5] = a[i + 4][0] = a[i + 4][1] = a[i + 4][2] = 0;
+		a[i][6] = -src[i].x * dst[i].x;
+		a[i][7] = -src[i].y * dst[i].x;
+		a[i + 4][6] = -src[i].x * dst[i].y;
+		a[i + 4][7] = -src[i].y * dst[i].y;
+		b[i] = dst[i].x;
+		b[i + 4] = dst[i].y;
+	}
+	Mat M(3, 3, CV_64FC1);
+	double* m = M.ptr<double>(0);
+	if (!shim_detail::lu_solve(&a[0][0], 8, b)) for (int i = 0; i < 8; ++i) b[i] = 0;
+	for (int i = 0; i < 8; ++i) m[i] = b[i];
+	m[8] = 1.;
+	return M;
+}
+
+// [assumed-OpenCV] imgwarp.cpp warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) for CV_8UC3: M inverted (closed form), then per 64x16
+// block (BLOCK_SZ 32 -> bh0 = 16, bw0 = 64) the source coordinate of every destination pixel in 1/32-pixel fixed point,
+//   X0 = M0*x + M1*(y+y1) + M2 at the block's left edge, fX = (X0 + M0*x1) * (32 / (W0 + M6*x1)), X = cvRound(fX),
+// and remap's fixed-point bilinear: weights (32-fx)(32-fy)*32 .. (sum 2^15), out = (sum w*p + 2^14) >> 15, taps outside the source = 0
+inline void warpPerspective(const Mat& src_, Mat& dst, const Mat& M0, Size dsize, int flags = INTER_LINEAR)
+{
+	if (src_.type() != CV_8UC3 || M0.type() != CV_64FC1 || (flags & 7) != INTER_LINEAR)
+	{ std::cerr << "cv-shim: warpPerspective: CV_8UC3, CV_64F matrix, INTER_LINEAR only" << std::endl; std::abort(); }
+	Mat src = src_.clone();
+	double Min[9], M[9];
+	for (int i = 0; i < 9; ++i) Min[i] = M0.ptr<double>(i / 3)[i % 3];
+	if (!shim_detail::invert3x3(Min, M)) for (int i = 0; i < 9; ++i) M[i] = 0;
+	const int width = dsize.width, height = dsize.height, sw = src.cols, sh = src.rows;
+	Mat out(height, width, CV_8UC3);
+	const int BLOCK_SZ = 32;
+	int bh0 = std::min(BLOCK_SZ / 2, height), bw0 = std::min(BLOCK_SZ * BLOCK_SZ / bh0, width);
+	bh0 = std::min(BLOCK_SZ * BLOCK_SZ / bw0, height);
+	for (int y = 0; y < height; y += bh0)
+		for (int x = 0; x < width; x += bw0)
+		{
+			const int bw = std::min(bw0, width - x), bh = std::min(bh0, height - y);
+			for (int y1 = 0; y1 < bh; ++y1)
+			{
+				const double X0 = M[0] * x + M[1] * (y + y1) + M[2];
+				const double Y0 = M[3] * x + M[4] * (y + y1) + M[5];
+				const double W0 = M[6] * x + M[7] * (y + y1) + M[8];
+				uchar* o = out.ptr<uchar>(y + y1) + (size_t)x * 3;
+				for (int x1 = 0; x1 < bw; ++x1)
+				{
+					double W = W0 + M[6] * x1;
+					W = W ? 32. / W : 0;
+					const double fX = std::max((double)INT_MIN, std::min((double)INT_MAX, (X0 + M[0] * x1) * W));
+					const double fY = std::max((double)INT_MIN, std::min((double)INT_MAX, (Y0 + M[3] * x1) * W));
+					const int X = cvRound(fX), Y = cvRound(fY);
+					auto sat16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+					const int sx = sat16(X >> 5), sy = sat16(Y >> 5), fx = X & 31, fy = Y & 31;
+					const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+					for (int c = 0; c < 3; ++c)
+					{
+						auto px = [&](int yy, int xx) -> int { return (xx < 0 || xx >= sw || yy < 0 || yy >= sh) ? 0 : src.ptr<uchar>(yy)[xx * 3 + c]; };
+						const int v = px(sy, sx) * w00 + px(sy, sx + 1) * w01 + px(sy + 1, sx) * w10 + px(sy + 1, sx + 1) * w11;
+						o[x1 * 3 + c] = (uchar)((v + (1 << 14)) >> 15);
+					}
+				}
+			}
+		}
+	dst = out;
 }
 
 }  // namespace cv

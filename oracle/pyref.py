@@ -27,11 +27,11 @@ _ref = None
 
 
 def build_oracle():
-    src = os.path.join(HERE, "cimbar_oracle.c")
+    srcs = [os.path.join(HERE, "cimbar_oracle.c"), os.path.join(HERE, "cimbar_oracle_extract.c")]
     hdr = os.path.join(HERE, "cimbar_oracle.h")
-    if os.path.exists(ORACLE_SO) and os.path.getmtime(ORACLE_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if os.path.exists(ORACLE_SO) and os.path.getmtime(ORACLE_SO) >= max(os.path.getmtime(p) for p in srcs + [hdr]):
         return ORACLE_SO
-    subprocess.run(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-std=gnu11", "-Wall", "-shared", "-o", ORACLE_SO, src, "-lm"], check=True)
+    subprocess.run(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-std=gnu11", "-Wall", "-shared", "-o", ORACLE_SO, *srcs, "-lm"], check=True)
     return ORACLE_SO
 
 

@@ -17,6 +17,10 @@
 #include "encoder/Encoder.h"
 #include "encoder/ReedSolomon.h"
 #include "encoder/escrow_buffer_writer.h"
+#include "extractor/Corners.h"
+#include "extractor/Deskewer.h"
+#include "extractor/Extractor.h"
+#include "extractor/Scanner.h"
 #include "fountain/fountain_decoder_sink.h"
 #include "fountain/fountain_encoder_stream.h"
 
@@ -307,5 +311,54 @@ int ref_sink_reset(unsigned chunk_size) { g_sink = std::make_shared<fountain_dec
 int64_t ref_sink_decode_frame(const uint8_t* buf, unsigned size) { return g_sink ? g_sink->decode_frame((const char*)buf, size) : -100; }
 int ref_sink_is_done(uint32_t id) { return g_sink && g_sink->is_done(id) ? 1 : 0; }
 int ref_sink_recover(uint32_t id, uint8_t* out, unsigned size) { return g_sink && g_sink->recover(id, out, size) ? 1 : 0; }
+
+
+// ---- the stage in front of the decoder: Scanner / Deskewer / Extractor on one RGB8 camera frame
+// Scanner::preprocess_image(img, fast=true) (Scanner.h:148-165): gray -> GaussianBlur -> Otsu threshold. out: w*h bytes (0 / 255)
+int ref_scan_preprocess(const uint8_t* rgb, unsigned w, unsigned h, uint8_t* out)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	cv::Mat bin = Scanner::preprocess_image(img, true);
+	for (int y = 0; y < bin.rows; ++y) std::memcpy(out + (size_t)y * w, bin.ptr<uchar>(y), w);
+	return 0;
+}
+
+// Scanner(img).scan() + Corners (Extractor.h:33-39): corners[8] = top_left, top_right, bottom_left, bottom_right (x, y). Returns the
+// number of anchors found (4 = success).
+int ref_scan_corners(const uint8_t* rgb, unsigned w, unsigned h, float* corners8)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	Scanner scanner(img);
+	std::vector<Anchor> points = scanner.scan();
+	if (points.size() < 4) return (int)points.size();
+	Corners corners(points);
+	std::vector<cv::Point2f> all = corners.all();
+	for (int i = 0; i < 4; ++i) { corners8[2 * i] = all[i].x; corners8[2 * i + 1] = all[i].y; }
+	return 4;
+}
+
+// Deskewer(0, image_size, anchor_size).deskew(img, corners) (Deskewer.h:26-40) for explicit corners: out = 1024*1024*3
+int ref_deskew(const uint8_t* rgb, unsigned w, unsigned h, const float* corners8, uint8_t* out)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	Corners corners(point<int>((int)corners8[0], (int)corners8[1]), point<int>((int)corners8[2], (int)corners8[3]),
+	                point<int>((int)corners8[4], (int)corners8[5]), point<int>((int)corners8[6], (int)corners8[7]));
+	Deskewer de;
+	cv::Mat res = de.deskew(img, corners);
+	for (int y = 0; y < res.rows; ++y) std::memcpy(out + (size_t)y * res.cols * 3, res.ptr<uchar>(y), (size_t)res.cols * 3);
+	return res.rows;
+}
+
+// Extractor::extract (Extractor.h:29-45): 0 failure, 1 success, 2 needs sharpen; out = the deskewed 1024x1024 RGB8 frame
+int ref_extract(const uint8_t* rgb, unsigned w, unsigned h, uint8_t* out)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	cv::Mat res;
+	Extractor ext;
+	int rc = ext.extract(img, res);
+	if (rc != Extractor::FAILURE)
+		for (int y = 0; y < res.rows; ++y) std::memcpy(out + (size_t)y * res.cols * 3, res.ptr<uchar>(y), (size_t)res.cols * 3);
+	return rc;
+}
 
 }  // extern "C"

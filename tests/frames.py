@@ -61,3 +61,28 @@ def distorted_set(synth, seed=77):
         ("noise200", add_noise(f[3], 200, 3)),
     ]
     return out
+
+
+def camera_frame(frame, width=1920, height=1080, quad=((500, 40), (1480, 70), (470, 1030), (1500, 1000)), background=96, blur=0.0):
+    """A synthetic camera capture: the 1024x1024 `frame` drawn into a width x height RGB image as the quadrilateral `quad`
+    (top-left, top-right, bottom-left, bottom-right corners in capture pixels) over a flat background -- what the Scanner / Deskewer
+    stage in front of the decoder has to undo."""
+    from PIL import Image, ImageFilter
+    n = frame.shape[0]
+    (x0, y0), (x1, y1), (x2, y2), (x3, y3) = quad
+    # PIL wants the map output(x,y) -> input: solve the homography that sends the quad's corners to the frame's corners
+    src = [(x0, y0), (x1, y1), (x2, y2), (x3, y3)]
+    dst = [(0, 0), (n, 0), (0, n), (n, n)]
+    A, b = [], []
+    for (x, y), (u, v) in zip(src, dst):
+        A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+        A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+    coeffs = np.linalg.solve(np.array(A, dtype=np.float64), np.array(b, dtype=np.float64))
+    im = Image.fromarray(frame).convert("RGBA")
+    warped = im.transform((width, height), Image.PERSPECTIVE, tuple(coeffs), Image.BILINEAR)
+    canvas = Image.new("RGBA", (width, height), (background, background, background, 255))
+    canvas.alpha_composite(warped)
+    out = canvas.convert("RGB")
+    if blur > 0:
+        out = out.filter(ImageFilter.GaussianBlur(blur))
+    return np.array(out)

@@ -114,3 +114,41 @@ def test_plain_decode_no_fountain_path(ref, oracle, synth, pre):
         assert (got == want).all(), name
         blocks = got.reshape(60, 125)
         assert all(ok[b] or not blocks[b].any() for b in range(60)), name
+
+
+CAMERA_CASES = [
+    # background, quad (tl, tr, bl, br) in a 1920x1080 capture, blur
+    (0, ((500, 40), (1480, 70), (470, 1030), (1500, 1000)), 0.0),
+    (255, ((430, 10), (1500, 30), (410, 1060), (1490, 1075)), 0.8),
+    (30, ((448, 28), (1472, 28), (448, 1052), (1472, 1052)), 0.0),
+    (12, ((520, 60), (1450, 40), (540, 1010), (1430, 1040)), 0.6),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CAMERA_CASES)))
+def test_extractor_stage_scan_preprocess_and_deskew(ref, oracle, synth, case):
+    """the oracle's restatement of Scanner::preprocess_image and Deskewer::deskew against the reference's own
+    Scanner / Deskewer / Extractor code (compiled against the cv-shim), and the whole reference chain capture -> extract -> decode"""
+    bg, quad, blur = CAMERA_CASES[case]
+    payload, frames = F.clean_frames(synth, 1, seed=50 + case)
+    cam = np.ascontiguousarray(F.camera_frame(frames[0], quad=quad, background=bg, blur=blur))
+    h, w = cam.shape[:2]
+    a, b = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+    ref.ref_scan_preprocess(P(cam), w, h, P(a))
+    assert 0 <= oracle.co_scan_preprocess(P(cam), w, h, P(b)) < 256
+    assert (a == b).all()
+    corners = (ctypes.c_float * 8)()
+    assert ref.ref_scan_corners(P(cam), w, h, corners) == 4
+    for (qx, qy), k in zip(quad, range(4)):      # anchor centres sit ~30/1024 of the way in from the quad's corners
+        assert abs(corners[2 * k] - qx) < 60 and abs(corners[2 * k + 1] - qy) < 60
+    o1, o2, o3 = (np.zeros((1024, 1024, 3), np.uint8) for _ in range(3))
+    assert ref.ref_deskew(P(cam), w, h, corners, P(o1)) == 1024
+    oracle.co_deskew(P(cam), w, h, corners, P(o2))
+    assert (o1 == o2).all()
+    rc = ref.ref_extract(P(cam), w, h, P(o3))
+    assert rc in (1, 2) and (o3 == o1).all()
+    r, chunks, mask = pyref.ref_decode(o3, rc == 2, 2, 1)           # cimbar.cpp:147-171: NEEDS_SHARPEN -> should_preprocess
+    r2, chunks2, mask2, _ = pyref.oracle_decode(o2, rc == 2, 2)
+    assert (r, mask) == (r2, mask2) and (chunks == chunks2).all()
+    if blur < 1.0:
+        assert r == 7500 and (chunks.reshape(-1) == payload[0]).all()
