@@ -118,6 +118,24 @@ int cimbar_hip_set_template(cimbar_hip_ctx* ctx, const uint8_t* rgb_template, in
 int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, int payload_mem, uint8_t* rgb_out, int rgb_mem,
                             void* hip_stream);
 
+/* ---- the stage in front of the decoder ("next" row 2 of the scope table: Scanner's image preparation + Deskewer) ----------------------
+ * The reference turns a camera capture into the decoder's 1024x1024 frame with Extractor::extract (src/lib/extractor/Extractor.h:29-45):
+ * Scanner (gray -> small Gaussian -> Otsu threshold, Scanner.h:148-165; then a sparse scan-line search for the four anchors on that
+ * binary image, Scanner.h:277-405) and Deskewer::deskew (cv::getPerspectiveTransform + cv::warpPerspective INTER_LINEAR,
+ * Deskewer.h:26-40). The two image passes are here; the anchor search stays host code on the binary image this returns (2 MB per
+ * 1080p capture instead of 6 MB), and its four corners come back for the warp, whose output can stay in device memory for
+ * cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated, see DESIGN.md.
+ *   cimbar_hip_scan_preprocess : n captures -> n * width * height bytes (0 / 255) = Scanner::preprocess_image(img, fast = true);
+ *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Short side above 3000 px: EDIM.
+ *   cimbar_hip_deskew_batch    : corners = n * 8 floats in HOST memory, per capture top-left, top-right, bottom-left, bottom-right (x, y)
+ *                                exactly as Corners::all() returns them (Corners.h:45-53); frames = n * 1024*1024*3 bytes = what
+ *                                Deskewer(0, {1024,1024}, 30).deskew(img, corners) returns.
+ * Buffers, stream and errors as for cimbar_hip_decode_batch (host outputs: synchronises; device outputs: enqueues and returns 0). */
+int cimbar_hip_scan_preprocess(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, int n, int rgb_mem,
+                               uint8_t* binary, int* thresholds, int out_mem, void* hip_stream);
+int cimbar_hip_deskew_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, int n, int rgb_mem,
+                            const float* corners, uint8_t* frames, int out_mem, void* hip_stream);
+
 /* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
 enum {
 	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */

@@ -18,10 +18,13 @@
 //   K3 k_rs             (colours: 20 blocks)
 //   K7 k_frame_end      aligned_stream bookkeeping for the colour chunks, chunk mask, zero dropped slots, CCM carry-out
 //   E1 k_rs_encode / E2 k_render   the encode half (Encoder::encode_next): RS encode + tile render
+//   X1-X4 k_scan_* / k_warp        the stage in front (Scanner's image preparation, Deskewer's perspective warp)
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
 #include <cfloat>
+#include <climits>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +83,7 @@ struct Tables {
 #include "k3_rs.hip.inc"
 #include "k4_frame.hip.inc"
 #include "encode.hip.inc"
+#include "extract.hip.inc"
 
 }  // namespace
 

@@ -25,6 +25,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
+    "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch",
 )
 
 
@@ -66,6 +67,10 @@ def load_library(path=None):
     lib.cimbar_hip_pipeline_wait.restype = i32
     lib.cimbar_hip_pipeline_depth.argtypes = [vp]
     lib.cimbar_hip_pipeline_depth.restype = i32
+    lib.cimbar_hip_scan_preprocess.argtypes = [vp, vp, u32, u32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_scan_preprocess.restype = i32
+    lib.cimbar_hip_deskew_batch.argtypes = [vp, vp, u32, u32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_deskew_batch.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -187,6 +192,34 @@ class HipDecoder:
     @property
     def pipeline_depth(self):
         return int(self._lib.cimbar_hip_pipeline_depth(self._ctx))
+
+    # ------------------------------------------------------------------ the stage in front: Scanner's image preparation, Deskewer
+    def scan_preprocess(self, captures):
+        """captures (n,h,w,3) uint8 numpy -> (binary (n,h,w) uint8 of 0/255, thresholds (n,) int32): Scanner::preprocess_image."""
+        captures = np.ascontiguousarray(captures, dtype=np.uint8)
+        n, h, w = captures.shape[:3]
+        out = np.zeros((n, h, w), dtype=np.uint8)
+        thr = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.cimbar_hip_scan_preprocess(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, out.ctypes.data, thr.ctypes.data,
+                                                         MEM_HOST, None), "cimbar_hip_scan_preprocess")
+        return out, thr
+
+    def deskew_batch(self, captures, corners):
+        """captures (n,h,w,3) uint8, corners (n,8) float32 (tl, tr, bl, br as x,y) -> frames (n,1024,1024,3): Deskewer::deskew."""
+        captures = np.ascontiguousarray(captures, dtype=np.uint8)
+        corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
+        n, h, w = captures.shape[:3]
+        out = np.zeros((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, corners.ctypes.data, out.ctypes.data,
+                                                      MEM_HOST, None), "cimbar_hip_deskew_batch")
+        return out
+
+    def deskew_batch_device(self, captures_ptr, w, h, n, corners, frames_ptr, stream=None):
+        """device captures -> device frames (what cimbar_hip_decode_batch takes next); corners stay a host array."""
+        corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
+        self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(n), MEM_DEVICE,
+                                                      corners.ctypes.data, ctypes.c_void_p(frames_ptr), MEM_DEVICE,
+                                                      ctypes.c_void_p(stream) if stream else None), "cimbar_hip_deskew_batch(device)")
 
     # ------------------------------------------------------------------ the reference's operator surface
     def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):

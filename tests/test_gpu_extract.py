@@ -1,0 +1,107 @@
+"""GPU: the stage in front of the decoder -- Scanner's image preparation and Deskewer's warp on synthetic camera
+captures, against the oracle's restatement (bit-exact), and the whole chain capture -> GPU preprocess -> [reference Scanner on the
+host] -> GPU deskew -> GPU decode against the reference's Extractor + Decoder. Parity with a real OpenCV is unpinned."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import decoder as D
+from libcimbar_amd import modeb
+from oracle import pyref
+from oracle.pyref import P
+from tests import frames as F
+from tests.test_oracle_vs_ref import CAMERA_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def captures(synth, size=(1920, 1080)):
+    payload, frames = F.clean_frames(synth, len(CAMERA_CASES), seed=90)
+    cams = [F.camera_frame(frames[k], width=size[0], height=size[1], quad=q, background=bg, blur=bl) for k, (bg, q, bl) in enumerate(CAMERA_CASES)]
+    return payload, np.ascontiguousarray(np.stack(cams))
+
+
+def test_scan_preprocess_matches_oracle(hip_decoder, synth, oracle):
+    _, cams = captures(synth)
+    got, thr = hip_decoder.scan_preprocess(cams)
+    for k in range(len(cams)):
+        want = np.zeros(cams[k].shape[:2], np.uint8)
+        t = oracle.co_scan_preprocess(P(cams[k]), cams.shape[2], cams.shape[1], P(want))
+        assert thr[k] == t
+        assert (got[k] == want).all(), f"capture {k}: {(got[k] != want).sum()} pixels differ"
+
+
+def test_scan_preprocess_5x5_blur_and_odd_sizes(hip_decoder, oracle):
+    rng = np.random.default_rng(4)
+    for (w, h) in ((2600, 1700), (1283, 977), (64, 40)):          # 5x5 kernel above 1500 px; sizes that are no multiple of the tile
+        img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+        img[0, : h // 2] //= 3
+        got, thr = hip_decoder.scan_preprocess(img)
+        want = np.zeros((h, w), np.uint8)
+        assert thr[0] == oracle.co_scan_preprocess(P(img[0]), w, h, P(want))
+        assert (got[0] == want).all(), (w, h)
+
+
+def test_deskew_matches_oracle_and_reference_chain(hip_decoder, synth, oracle, ref):
+    payload, cams = captures(synth)
+    n, h, w = cams.shape[:3]
+    corners = np.zeros((n, 8), np.float32)
+    for k in range(n):          # the anchor search is the reference's host code, fed with the capture as the reference feeds it
+        c = (ctypes.c_float * 8)()
+        assert ref.ref_scan_corners(P(cams[k]), w, h, c) == 4
+        corners[k] = list(c)
+    frames = hip_decoder.deskew_batch(cams, corners)
+    for k in range(n):
+        want = np.zeros((1024, 1024, 3), np.uint8)
+        oracle.co_deskew(P(cams[k]), w, h, corners[k].ctypes.data_as(ctypes.POINTER(ctypes.c_float)), P(want))
+        assert (frames[k] == want).all(), f"capture {k}: {(frames[k] != want).sum()} bytes differ"
+    # ... and on through the decoder: same chunks as Extractor::extract + Decoder::decode_fountain of the reference build
+    full = 0
+    for k in range(n):
+        ext = np.zeros((1024, 1024, 3), np.uint8)
+        rc = ref.ref_extract(P(cams[k]), w, h, P(ext))
+        assert rc in (1, 2) and (ext == frames[k]).all()
+        r, chunks, mask = pyref.ref_decode(ext, rc == 2, 2, 1)
+        hip_decoder.reset_ccm()
+        good, got, gmask = hip_decoder.decode_frame(frames[k], rc == 2, 2)
+        assert (good, gmask) == (r, mask) and (got == chunks).all()
+        full += int(good == 7500 and (got.reshape(-1) == payload[k]).all())
+    assert full >= 1      # (whether a given capture survives is the reference's business; agreeing with it is ours)
+
+
+def test_deskew_to_decode_without_leaving_the_device(hip_decoder, synth, ref):
+    payload, cams = captures(synth)
+    n, h, w = cams.shape[:3]
+    corners = np.zeros((n, 8), np.float32)
+    for k in range(n):
+        c = (ctypes.c_float * 8)()
+        assert ref.ref_scan_corners(P(cams[k]), w, h, c) == 4
+        corners[k] = list(c)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    d_cams = torch.from_numpy(cams).to(dev)
+    d_frames = torch.empty((n, 1024, 1024, 3), dtype=torch.uint8, device=dev)
+    chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+    hip_decoder.reset_ccm()
+    hip_decoder.deskew_batch_device(d_cams.data_ptr(), w, h, n, corners, d_frames.data_ptr(), st)
+    hip_decoder.decode_batch_device(d_frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), True, 2, st)   # upscaled captures: sharpen
+    torch.cuda.synchronize()
+    hip_decoder.reset_ccm()
+    for k in range(n):          # the same frames through the host entry points
+        fr = hip_decoder.deskew_batch(cams[k:k + 1], corners[k:k + 1])
+        assert (fr[0] == d_frames[k].cpu().numpy()).all()
+    want_total, want_chunks, want_masks = hip_decoder.decode_batch(d_frames.cpu().numpy(), True, 2)
+    assert (want_masks.astype(np.int64) == masks.cpu().numpy().astype(np.int64)).all()
+    assert (want_chunks.reshape(n, -1) == chunks.cpu().numpy()).all()
+
+
+def test_extract_stage_bad_arguments(hip_decoder):
+    lib = D.load_library()
+    buf = np.zeros((40, 64, 3), np.uint8)
+    out = np.zeros((40, 64), np.uint8)
+    assert lib.cimbar_hip_scan_preprocess(hip_decoder._ctx, None, 64, 40, 1, D.MEM_HOST, out.ctypes.data, None, D.MEM_HOST, None) == -1
+    assert lib.cimbar_hip_scan_preprocess(hip_decoder._ctx, buf.ctypes.data, 64, 40, 0, D.MEM_HOST, out.ctypes.data, None, D.MEM_HOST, None) == -1
+    assert lib.cimbar_hip_deskew_batch(hip_decoder._ctx, buf.ctypes.data, 64, 40, 1, D.MEM_HOST, None, out.ctypes.data, D.MEM_HOST, None) == -1
