@@ -47,3 +47,28 @@ for name, buf in (("pageable", h.numpy()), ("pinned", h.pin_memory().numpy())):
     dec.decode_batch(buf[:8])
     t0 = time.perf_counter(); total, chunks, masks = dec.decode_batch(buf); dt = time.perf_counter() - t0
     print(f"host-fed {name}: 256 frames in {dt*1e3:.1f} ms = {256/dt:.0f} frames/s ({256*3.145728/dt/1e3:.1f} GB/s over PCIe), good bytes {total}")
+
+# the stage in front of the decoder: 1080p captures resident in HBM -> binary image for the scanner; -> deskewed 1024x1024 frames
+import ctypes
+from libcimbar_amd import decoder as D
+ncap, W, H = 256, 1920, 1080
+caps = torch.zeros((ncap, H, W, 3), dtype=torch.uint8, device=dev)
+caps[:, 28:1052, 448:1472] = frames[:ncap]                    # the frame pasted upright into a dark capture
+binimg = torch.empty((ncap, H, W), dtype=torch.uint8, device=dev)
+out = torch.empty((ncap, 1024, 1024, 3), dtype=torch.uint8, device=dev)
+corners = np.tile(np.array([478, 58, 1442, 58, 478, 1022, 1442, 1022], np.float32), (ncap, 1))   # anchor centres of that paste
+lib = D.load_library()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+for it in range(3):
+    ev[0].record()
+    rc = lib.cimbar_hip_scan_preprocess(dec._ctx, ctypes.c_void_p(caps.data_ptr()), W, H, ncap, 1, ctypes.c_void_p(binimg.data_ptr()), None, 1, None)
+    ev[1].record()
+    dec.deskew_batch_device(caps.data_ptr(), W, H, ncap, corners, out.data_ptr(), None)
+    ev[2].record()
+    torch.cuda.synchronize()
+t_pre, t_warp = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+chunks = torch.zeros((ncap, 7500), dtype=torch.uint8, device=dev); masks = torch.zeros((ncap,), dtype=torch.int32, device=dev)
+dec.decode_batch_device(out.data_ptr(), ncap, chunks.data_ptr(), masks.data_ptr(), False, 2, None); torch.cuda.synchronize()
+print(f"extract stage, {ncap} captures 1920x1080: scan_preprocess {t_pre:.3f} ms ({ncap/t_pre*1e3:.0f} captures/s, "
+      f"{ncap*(W*H*4)/t_pre/1e6:.0f} GB/s rd+wr), deskew {t_warp:.3f} ms ({ncap/t_warp*1e3:.0f} captures/s); "
+      f"deskewed frames decode: {int((masks == 0xFFF).sum())}/{ncap} complete, payload ok {bool((chunks == payload[:ncap]).all())}")
