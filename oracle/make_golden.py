@@ -65,6 +65,22 @@ def main():
         c = run_case(L, cf[0], 0, cc)
         c.update(name=f"clean_cc{cc}", preprocess=0, color_correction=cc)
         out["cases"].append(c)
+    # the stage in front of the decoder (Scanner / Deskewer / Extractor of the reference build) on synthetic camera captures
+    from tests.test_oracle_vs_ref import CAMERA_CASES
+    ex = []
+    for k, (bg, quad, blur) in enumerate(CAMERA_CASES):
+        _, fr = F.clean_frames(synth, 1, seed=50 + k)
+        cam = np.ascontiguousarray(F.camera_frame(fr[0], quad=quad, background=bg, blur=blur))
+        h, w = cam.shape[:2]
+        binimg = np.zeros((h, w), np.uint8)
+        L.ref_scan_preprocess(P(cam), w, h, P(binimg))
+        corners = (ctypes.c_float * 8)()
+        nanch = L.ref_scan_corners(P(cam), w, h, corners)
+        desk = np.zeros((1024, 1024, 3), np.uint8)
+        rc = L.ref_extract(P(cam), w, h, P(desk))
+        ex.append({"case": k, "input_sha256": sha(cam), "width": w, "height": h, "binary_sha256": sha(binimg), "anchors": int(nanch),
+                   "corners": [float(c) for c in corners], "extract_rc": int(rc), "deskewed_sha256": sha(desk)})
+    out["extract"] = ex
     # Reed-Solomon known answers straight from libcorrect: 40 random blocks with 0..22 byte errors
     g = np.random.default_rng(2024)
     rs = []

@@ -40,3 +40,18 @@ def test_hip_matches_reference_fixture(case, golden_inputs, hip_decoder):
     hip_decoder.reset_ccm()
     pr, plain, _ = hip_decoder.decode_plain_batch(frame[None], bool(case["preprocess"]), case["color_correction"])   # Decoder::decode
     assert pr == case["plain_ret"] and sha(plain[0]) == case["plain_sha256"]
+
+
+@pytest.mark.parametrize("entry", GOLDEN.get("extract", []), ids=lambda e: f"capture{e['case']}")
+def test_hip_extract_stage_matches_reference_fixture(entry, synth, hip_decoder):
+    """scan_preprocess / deskew_batch against what the reference's Scanner / Extractor produced in the build container (no oracle/_ref needed)"""
+    from tests.test_oracle_vs_ref import CAMERA_CASES
+    bg, quad, blur = CAMERA_CASES[entry["case"]]
+    _, fr = F.clean_frames(synth, 1, seed=50 + entry["case"])
+    cam = np.ascontiguousarray(F.camera_frame(fr[0], quad=quad, background=bg, blur=blur))
+    if sha(cam) != entry["input_sha256"]:
+        pytest.skip("input regeneration differs on this host (PIL version) -- fixture not applicable")
+    binimg, _ = hip_decoder.scan_preprocess(cam[None])
+    assert sha(binimg[0]) == entry["binary_sha256"]
+    desk = hip_decoder.deskew_batch(cam[None], np.array(entry["corners"], np.float32)[None])
+    assert sha(desk[0]) == entry["deskewed_sha256"]

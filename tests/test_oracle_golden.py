@@ -189,3 +189,22 @@ def test_ccm_known_answers_printed_by_a_real_opencv(oracle):
     for actual, want in cases:
         oracle.co_moore_penrose_lsm(F15(*actual), F15(*desired), 5, out)
         assert _cvfmt(list(out)) == want
+
+
+@pytest.mark.parametrize("entry", GOLDEN.get("extract", []), ids=lambda e: f"capture{e['case']}")
+def test_extract_stage_matches_reference_fixture(entry, synth, oracle):
+    """the oracle's Scanner::preprocess_image / Deskewer::deskew restatement against what the reference build produced (tests/golden)"""
+    from tests.test_oracle_vs_ref import CAMERA_CASES
+    bg, quad, blur = CAMERA_CASES[entry["case"]]
+    _, fr = F.clean_frames(synth, 1, seed=50 + entry["case"])
+    cam = np.ascontiguousarray(F.camera_frame(fr[0], quad=quad, background=bg, blur=blur))
+    if sha(cam) != entry["input_sha256"]:
+        pytest.skip("input regeneration differs on this host (PIL version) -- fixture not applicable")
+    h, w = cam.shape[:2]
+    binimg = np.zeros((h, w), np.uint8)
+    oracle.co_scan_preprocess(P(cam), w, h, P(binimg))
+    assert sha(binimg) == entry["binary_sha256"]
+    corners = (ctypes.c_float * 8)(*entry["corners"])
+    desk = np.zeros((1024, 1024, 3), np.uint8)
+    oracle.co_deskew(P(cam), w, h, corners, P(desk))
+    assert sha(desk) == entry["deskewed_sha256"]
