@@ -46,3 +46,15 @@ def test_product_never_touches_the_oracle():
                     text = open(os.path.join(dirpath, fn), errors="replace").read()
                     for pat in pats:
                         assert not re.search(pat, text, flags=re.M), (fn, pat)
+
+
+def test_cpp_adapter_and_its_test_program_compile():
+    """the header-only C++ adapter (libcimbar_amd/host/Decoder.h) and the program the GPU test runs are at least well-formed C++17
+    against include/cimbar_hip.h on any machine (the GPU box builds and runs them, tests/test_gpu_cpp_adapter.py)"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp")
+    res = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", src], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    hdr = os.path.join(ROOT, "include", "cimbar_hip.h")
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr      # the public header is plain C
