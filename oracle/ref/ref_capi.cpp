@@ -361,4 +361,31 @@ int ref_extract(const uint8_t* rgb, unsigned w, unsigned h, uint8_t* out)
 	return rc;
 }
 
+
+// The body of CimbDecoderTest/testPrethresholdDecode (cimb_translator/test/CimbDecoderTest.cpp:49-75), run against the cv-shim: every tile,
+// embedded in a 10x10 window, goes through cvtColor(RGB2GRAY) + adaptiveThreshold(MEAN_C, blockSize 9, C 0) + mat_to_bitbuffer and must
+// decode to itself at the centre with distance 0 -- which the reference's CI establishes for a real OpenCV. Returns the number of tiles
+// (0..16) for which the shim reproduces that; out3[3*i..] = symbol, drift_offset, distance.
+int ref_prethreshold_decode_test(unsigned* out3)
+{
+	CimbDecoder cd(4, 0, true, 0xFF);
+	int good = 0;
+	for (unsigned i = 0; i < 16; ++i)
+	{
+		cv::Mat tile = cimbar::getTile(4, i, true);
+		cv::Mat tenxten(10, 10, tile.type(), cv::Scalar(0, 0, 0));
+		tile.copyTo(tenxten(cv::Rect(1, 1, tile.cols, tile.rows)));
+		cv::cvtColor(tenxten, tenxten, cv::COLOR_RGB2GRAY);
+		cv::adaptiveThreshold(tenxten, tenxten, 255, cv::ADAPTIVE_THRESH_MEAN_C, cv::THRESH_BINARY, 9, 0);
+		bitbuffer bb((100 / 8) + 1);
+		bitmatrix::mat_to_bitbuffer(tenxten, bb.get_writer());
+		bitmatrix bm(bb, 10, 10);
+		unsigned drift_offset = 99, distance = 99;
+		unsigned res = cd.decode_symbol(bm, drift_offset, distance);
+		if (out3) { out3[3 * i] = res; out3[3 * i + 1] = drift_offset; out3[3 * i + 2] = distance; }
+		good += (res == i && drift_offset == 4 && distance == 0) ? 1 : 0;
+	}
+	return good;
+}
+
 }  // extern "C"

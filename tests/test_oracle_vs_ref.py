@@ -152,3 +152,12 @@ def test_extractor_stage_scan_preprocess_and_deskew(ref, oracle, synth, case):
     assert (r, mask) == (r2, mask2) and (chunks == chunks2).all()
     if blur < 1.0:
         assert r == 7500 and (chunks.reshape(-1) == payload[0]).all()
+
+
+def test_cvshim_reproduces_the_reference_prethreshold_decode_test(ref):
+    """cimb_translator/test/CimbDecoderTest.cpp:49-75 (testPrethresholdDecode) passes in the reference's CI with a real OpenCV: every tile
+    through cvtColor(RGB2GRAY) + adaptiveThreshold(MEAN_C, 9, 0) + mat_to_bitbuffer decodes to itself, centre window, distance 0 -- all 64
+    bits of all 16 tiles. The cv-shim's restatement of those two calls gives the same outcome (a behavioural pin, not a bit-level one)."""
+    out = (ctypes.c_uint * 48)()
+    assert ref.ref_prethreshold_decode_test(out) == 16, list(out)
+    assert [out[3 * i] for i in range(16)] == list(range(16))
