@@ -161,3 +161,48 @@ def test_cvshim_reproduces_the_reference_prethreshold_decode_test(ref):
     out = (ctypes.c_uint * 48)()
     assert ref.ref_prethreshold_decode_test(out) == 16, list(out)
     assert [out[3 * i] for i in range(16)] == list(range(16))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_distortions_oracle_equals_reference(ref, synth, seed):
+    """random combinations of shift, rescale, noise and wipe-outs: every stage of the oracle against the reference build"""
+    rng = np.random.default_rng(1000 + seed)
+    payload, frames = F.clean_frames(synth, 1, seed=2000 + seed)
+    fr = frames[0]
+    if rng.random() < 0.6:
+        fr = F.shift(fr, int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
+    if rng.random() < 0.4:
+        fr = F.rescale(fr, int(rng.integers(2, 9)))
+    if rng.random() < 0.7:
+        fr = F.add_noise(fr, float(rng.integers(10, 140)), int(rng.integers(0, 1 << 30)))
+    if rng.random() < 0.3:
+        y0, x0 = int(rng.integers(0, 900)), int(rng.integers(0, 900))
+        fr = F.blank_region(fr, y0, y0 + int(rng.integers(20, 120)), x0, x0 + int(rng.integers(20, 400)), value=int(rng.integers(0, 256)))
+    fr = np.ascontiguousarray(fr)
+    for pre in (0, 1):
+        r, chunks, mask = pyref.ref_decode(fr, pre, 2, 1)
+        r2, chunks2, mask2, _ = pyref.oracle_decode(fr, pre, 2)
+        assert (r, mask) == (r2, mask2) and (chunks == chunks2).all(), (seed, pre)
+        pr, plain = pyref.ref_decode_plain(fr, pre, 2, 1)
+        pr2, plain2, _, _ = pyref.oracle_decode_plain(fr, pre, 2)
+        assert pr == pr2 and (plain == plain2).all(), (seed, pre)
+
+
+@pytest.mark.parametrize("size,quad", [((1280, 720), ((300, 10), (990, 20), (290, 700), (1000, 690))),
+                                        ((3840, 2160), ((900, 60), (2950, 100), (880, 2090), (2980, 2050)))])
+def test_extractor_stage_other_capture_sizes(ref, oracle, synth, size, quad):
+    """720p (3x3 blur, heavy downscale) and 2160p (5x5 blur): preprocessing and warp of the oracle against the reference build"""
+    w, h = size
+    payload, frames = F.clean_frames(synth, 1, seed=77)
+    cam = np.ascontiguousarray(F.camera_frame(frames[0], width=w, height=h, quad=quad, background=0))
+    a, b = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+    ref.ref_scan_preprocess(P(cam), w, h, P(a))
+    assert oracle.co_scan_preprocess(P(cam), w, h, P(b)) >= 0
+    assert (a == b).all()
+    corners = (ctypes.c_float * 8)()
+    if ref.ref_scan_corners(P(cam), w, h, corners) != 4:      # (a capture the scanner cannot lock onto still has a well-defined warp)
+        corners = (ctypes.c_float * 8)(*[float(v) for p in quad for v in p])
+    o1, o2 = np.zeros((1024, 1024, 3), np.uint8), np.zeros((1024, 1024, 3), np.uint8)
+    ref.ref_deskew(P(cam), w, h, corners, P(o1))
+    oracle.co_deskew(P(cam), w, h, corners, P(o2))
+    assert (o1 == o2).all()
