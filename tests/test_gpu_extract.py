@@ -105,3 +105,26 @@ def test_extract_stage_bad_arguments(hip_decoder):
     assert lib.cimbar_hip_scan_preprocess(hip_decoder._ctx, None, 64, 40, 1, D.MEM_HOST, out.ctypes.data, None, D.MEM_HOST, None) == -1
     assert lib.cimbar_hip_scan_preprocess(hip_decoder._ctx, buf.ctypes.data, 64, 40, 0, D.MEM_HOST, out.ctypes.data, None, D.MEM_HOST, None) == -1
     assert lib.cimbar_hip_deskew_batch(hip_decoder._ctx, buf.ctypes.data, 64, 40, 1, D.MEM_HOST, None, out.ctypes.data, D.MEM_HOST, None) == -1
+
+
+@pytest.mark.parametrize("size,quad", [((1280, 720), ((300, 10), (990, 20), (290, 700), (1000, 690))),
+                                        ((3840, 2160), ((900, 60), (2950, 100), (880, 2090), (2980, 2050)))])
+def test_other_capture_sizes_match_oracle(hip_decoder, synth, oracle, size, quad):
+    """720p (3x3 blur, the warp upscales) and 2160p (5x5 blur, the warp shrinks): both passes against the oracle, corners from the quad"""
+    w, h = size
+    _, frames = F.clean_frames(synth, 1, seed=77)
+    cam = np.ascontiguousarray(F.camera_frame(frames[0], width=w, height=h, quad=quad, background=0))
+    got, thr = hip_decoder.scan_preprocess(cam[None])
+    want = np.zeros((h, w), np.uint8)
+    assert thr[0] == oracle.co_scan_preprocess(P(cam), w, h, P(want))
+    assert (got[0] == want).all()
+    corners = np.array([float(v) for p in quad for v in p], np.float32)
+    desk = hip_decoder.deskew_batch(cam[None], corners[None])
+    wantd = np.zeros((1024, 1024, 3), np.uint8)
+    oracle.co_deskew(P(cam), w, h, corners.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), P(wantd))
+    assert (desk[0] == wantd).all(), f"{(desk[0] != wantd).sum()} bytes differ"
+    # corners that push part of the frame outside the capture: out-of-image taps read 0
+    far = corners.copy(); far[0] -= 400; far[1] -= 300
+    desk = hip_decoder.deskew_batch(cam[None], far[None])
+    oracle.co_deskew(P(cam), w, h, far.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), P(wantd))
+    assert (desk[0] == wantd).all()
