@@ -9,6 +9,8 @@
 //                                                                escrow_buffer_writer, null_stream -- used UNCHANGED
 //     class CimbReader         src/lib/cimb_translator/          cimbar_amd::CimbReader        (read / read_color / done / num_reads over the
 //                              CimbReader.h:13-41                                               GPU's per-cell results, linear cell order)
+//     class Deskewer           src/lib/extractor/Deskewer.h:12-40 cimbar_amd::Deskewer          (deskew(img, corners) -> 1024x1024 frame; plus
+//     Scanner::preprocess_image src/lib/extractor/Scanner.h:148-165                              scan_preprocess(img) -> the binary image Scanner scans)
 //
 // Header-only; link against libcimbar_hip.so. No exceptions, no OpenCV requirement: MAT is anything shaped like cv::Mat
 // (`data`, `cols`, `rows`, `step`), e.g. cv::Mat, cv::UMat::getMat(), or cimbar_amd::image_view below.
@@ -193,6 +195,80 @@ protected:
 	unsigned _next = 0;
 	std::vector<unsigned char> _symbols, _colors;
 	std::vector<signed char> _drift;
+};
+
+// an owning 8-bit image (what the reference returns as a cv::Mat): shaped like image_view, so it can go straight back into decode()
+struct image
+{
+	std::vector<unsigned char> pixels;
+	unsigned char* data = nullptr;
+	int cols = 0;
+	int rows = 0;
+	size_t step = 0;
+	int channels = 0;
+	image() {}
+	image(int w, int h, int c) : pixels((size_t)w * h * c), data(nullptr), cols(w), rows(h), step((size_t)w * c), channels(c) { data = pixels.data(); }
+	image(const image& o) : pixels(o.pixels), data(nullptr), cols(o.cols), rows(o.rows), step(o.step), channels(o.channels) { data = pixels.data(); }
+	image& operator=(const image& o) { pixels = o.pixels; data = pixels.data(); cols = o.cols; rows = o.rows; step = o.step; channels = o.channels; return *this; }
+	bool empty() const { return pixels.empty(); }
+};
+
+// Deskewer (Deskewer.h:12-40) and the image preparation of Scanner (Scanner.h:148-165) over the context of a cimbar_amd::Decoder.
+// CORNERS is anything with all() returning four points with float-convertible .x / .y in the order top-left, top-right, bottom-left,
+// bottom-right -- the reference's Corners (Corners.h:45-53) as is.
+class Deskewer
+{
+public:
+	explicit Deskewer(Decoder& decoder) : _dec(decoder) {}
+
+	// Deskewer::deskew(img, corners): an empty image on failure
+	template <typename MAT, typename CORNERS>
+	image deskew(const MAT& img, const CORNERS& corners)
+	{
+		image out;
+		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return out;
+		float c8[8];
+		const auto pts = corners.all();
+		if (pts.size() != 4) return out;
+		for (int i = 0; i < 4; ++i) { c8[2 * i] = (float)pts[i].x; c8[2 * i + 1] = (float)pts[i].y; }
+		std::vector<unsigned char> packed;
+		const unsigned char* src = dense_rgb(img, packed);
+		out = image(CIMBAR_HIP_FRAME_DIM, CIMBAR_HIP_FRAME_DIM, 3);
+		if (cimbar_hip_deskew_batch(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, c8, out.data,
+		                            CIMBAR_HIP_MEM_HOST, nullptr) != 0)
+			out = image();
+		return out;
+	}
+
+	// Scanner::preprocess_image(img, fast = true): 0 / 255 per pixel, what Scanner::scan works on
+	template <typename MAT>
+	image scan_preprocess(const MAT& img)
+	{
+		image out;
+		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return out;
+		std::vector<unsigned char> packed;
+		const unsigned char* src = dense_rgb(img, packed);
+		out = image(img.cols, img.rows, 1);
+		if (cimbar_hip_scan_preprocess(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, out.data, nullptr,
+		                               CIMBAR_HIP_MEM_HOST, nullptr) != 0)
+			out = image();
+		return out;
+	}
+
+protected:
+	template <typename MAT>
+	static const unsigned char* dense_rgb(const MAT& img, std::vector<unsigned char>& packed)
+	{
+		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
+		const size_t dense = (size_t)img.cols * 3, step = (size_t)img.step ? (size_t)img.step : dense;
+		if (step == dense) return src;
+		packed.resize(dense * (size_t)img.rows);
+		for (int y = 0; y < img.rows; ++y)
+			for (size_t k = 0; k < dense; ++k) packed[(size_t)y * dense + k] = src[(size_t)y * step + k];
+		return packed.data();
+	}
+
+	Decoder& _dec;
 };
 
 }  // namespace cimbar_amd

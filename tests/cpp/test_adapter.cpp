@@ -83,6 +83,28 @@ int main(int argc, char** argv)
 	cimbar_amd::image_view small{frames.data(), 512, 512, 512 * 3};
 	CHECK(dec.decode_fountain(small, sink2) == 0 && dec.error_code() == CIMBAR_HIP_EDIM);
 
+	// the stage in front (Deskewer.h:26-40, Scanner.h:148-165): paste frame 0 upright into a dark 1920x1080 capture, deskew it from the
+	// anchor centres of that paste, decode the result
+	{
+		const int W = 1920, H = 1080, X0 = 448, Y0 = 28;
+		std::vector<unsigned char> cap((size_t)W * H * 3, 0);
+		for (int y = 0; y < 1024; ++y) std::memcpy(&cap[((size_t)(Y0 + y) * W + X0) * 3], frames.data() + (size_t)y * 1024 * 3, 1024 * 3);
+		cimbar_amd::image_view capture{cap.data(), W, H, 0};
+		struct pt { float x, y; };
+		struct four { std::vector<pt> all() const { return {{478, 58}, {1442, 58}, {478, 1022}, {1442, 1022}}; } } corners;
+		cimbar_amd::Deskewer de(dec);
+		cimbar_amd::image bin = de.scan_preprocess(capture);
+		CHECK(!bin.empty() && bin.cols == W && bin.rows == H);
+		size_t on = 0;
+		for (unsigned char v : bin.pixels) { CHECK(v == 0 || v == 255); on += v ? 1 : 0; }
+		CHECK(on > 100000 && on < (size_t)W * H / 2);
+		cimbar_amd::image fr = de.deskew(capture, corners);
+		CHECK(!fr.empty() && fr.cols == 1024 && fr.rows == 1024);
+		collecting_sink sink3(625);
+		CHECK(dec.decode_fountain(fr, sink3) == 7500);
+		CHECK(std::memcmp(sink3.bytes.data(), payload.data(), 7500) == 0);
+	}
+
 	// unsupported configuration -> !good(), decodes nothing
 	cimbar_amd::Decoder no_ecc(false, true);
 	CHECK(!no_ecc.good() && no_ecc.decode_fountain(img0, sink2) == 0);
