@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- decoded cimbar frames/s (1024x1024 mode B) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config 2|4]
 
 One "step" = one pass of the whole decode path (threshold -> symbols -> RS -> CCM -> colours -> RS -> chunks) over one
-device-resident batch of F synthetic clean mode-B frames (BASELINE.json configs[1]: F = 1024). For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank decodes its own F frames (weak scaling) and the step ends with the
-gather of the decoded chunks to rank 0 over RCCL. Rank 0 prints ONE JSON line.
+device-resident batch of F synthetic clean mode-B frames (BASELINE.json configs[1]: F = 1024). Consecutive steps decode
+DIFFERENT batches (D = pipeline depth distinct inputs are rotated), so that steps in flight never share input cache lines.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank decodes its own F frames (weak scaling) and the
+step ends with the gather of the decoded chunks to rank 0 over RCCL. Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
   roofline      dominant kernel's ALGORITHMIC bytes/s (3 153 232 B per frame) vs 8 TB/s HBM, timed live
                 with HIP events on the launch stream inside the library
   cpu_baseline  the CPU decoder timed on this host on a bounded sample of the same frames ("reference" = the
-                reference's own sources built into oracle/_ref, else "port" = oracle/cimbar_oracle.c)
+                reference's own sources built into oracle/_ref, else "port" = oracle/cimbar_oracle.c); its chunks' SHA-256
+                is compared with the GPU's chunks for the same frames (payload_sha_match)
+  no_pipeline   the same steps through the ordinary (un-pipelined) entry point
+  extra         N = 1 only: BASELINE configs[2] (99 substituted cells per frame), host-fed decode (pinned host frames in,
+                H2D inside the timed region), the extractor chain of configs[4] (1080p captures -> scan -> deskew -> decode)
+--config 4 runs BASELINE configs[3] instead (strong scaling: an 8192-frame fountain stream of a 16 MiB file split over the
+ranks, gather, rank-0 wirehair sink fed inside the timed region): see bench_config4().
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,16 +41,17 @@ ALGO_BYTES_PER_FRAME = modeb.FRAME_RGB_BYTES + modeb.FRAME_BYTES + 4   # 3 153 2
 HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_frames(n, device, seed, dec):
+def make_frames(n, device, seed, dec, check=True):
     """Synthetic clean mode-B frames, rendered on the device by the library's encode half (cimbar_hip_encode_batch, checked
     byte-for-byte against the reference encoder in tests/test_gpu_encode.py); 16 of them are cross-checked here against the
     torch restatement of Encoder::encode_next."""
     payload = framegen.synth_payload(n, seed=seed, device=device)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=device)
     dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
-    k = min(n, 16)
-    if not bool((frames[:k] == framegen.FrameSynth(device).frames_from_payload(payload[:k])).all().item()):
-        raise SystemExit("bench: device-rendered frames differ from the reference layout")
+    if check:
+        k = min(n, 16)
+        if not bool((frames[:k] == framegen.FrameSynth(device).frames_from_payload(payload[:k])).all().item()):
+            raise SystemExit("bench: device-rendered frames differ from the reference layout")
     return payload, frames
 
 
@@ -65,8 +74,9 @@ def measured_traffic(kernel, n):
         return None, None
 
 
-def cpu_baseline(frames_host, budget_s=15.0):
-    """Time the CPU decoder on host cores over a bounded sample of the same frames."""
+def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
+    """Time the CPU decoder on host cores over a bounded sample of the same frames, and compare what it decodes with the
+    GPU's chunks for those frames (SHA-256 over the sample's 12 x 625-byte chunk slots, frame order)."""
     from oracle import pyref
     import ctypes
     ref = pyref.ref_lib()
@@ -75,21 +85,27 @@ def cpu_baseline(frames_host, budget_s=15.0):
     ncores = os.cpu_count() or 1
     threads = max(1, min(ncores, 32, len(frames_host)))
 
-    def decode_one(fr, state):
-        if ref is not None:
+    def decode_one(fr, state, chunks=None):
+        if chunks is None:
             chunks = np.zeros(7500, np.uint8)
-            mask = ctypes.c_uint32(0)
-            return ref.ref_decode_fountain(pyref.P(fr), 1024, 1024, 0, 2, 0, pyref.P(chunks), ctypes.byref(mask))
-        chunks = np.zeros(7500, np.uint8)
         mask = ctypes.c_uint32(0)
+        if ref is not None:
+            return ref.ref_decode_fountain(pyref.P(fr), 1024, 1024, 0, 2, 0, pyref.P(chunks), ctypes.byref(mask))
         return orc.co_decode_fountain(pyref.P(fr), 1024, 1024, 0, 2, ctypes.byref(state), pyref.P(chunks), ctypes.byref(mask))
 
-    # single-thread probe sizes the sample
+    # what the CPU decoder makes of the sample, frame by frame on one thread (CCM carried in frame order, like the GPU batch)
     st = pyref.CoCcm()
+    if ref is not None:
+        ref.ref_reset_ccm()
+    cpu_chunks = np.zeros((len(frames_host), 7500), np.uint8)
     t0 = time.perf_counter()
-    decode_one(frames_host[0], st)
-    decode_one(frames_host[0], st)
-    per_frame = (time.perf_counter() - t0) / 2
+    for k in range(len(frames_host)):
+        if decode_one(frames_host[k], st, cpu_chunks[k]) != 7500:
+            raise RuntimeError("cpu baseline decoded a clean frame incorrectly")
+    per_frame = (time.perf_counter() - t0) / len(frames_host)
+    sha_cpu = hashlib.sha256(cpu_chunks.tobytes()).hexdigest()
+    sha_gpu = hashlib.sha256(np.ascontiguousarray(gpu_chunks).tobytes()).hexdigest()
+
     total = int(max(threads, 0.6 * budget_s / per_frame * threads))   # threads contend for memory bandwidth: ~60 % of ideal scaling
     done = [0] * threads
 
@@ -107,9 +123,106 @@ def cpu_baseline(frames_host, budget_s=15.0):
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": threads, "kind": kind,
-            "sample": f"{sum(done)} clean mode-B 1024x1024 frames from the bench batch, {threads} threads x 1 decoder each, "
-                      f"{dt:.1f} s wall, single-thread {1.0 / per_frame:.1f} frames/s"}
+    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": ncores, "threads": threads, "kind": kind,
+            "sample": f"{sum(done)} clean mode-B 1024x1024 frames from the bench batch ({len(frames_host)} distinct), {threads} threads x 1 "
+                      f"decoder each on a {ncores}-core host, {dt:.1f} s wall, single-thread {1.0 / per_frame:.1f} frames/s",
+            "payload_sha_match": sha_cpu == sha_gpu, "payload_sha256": sha_cpu}
+
+
+def stream_ms(dec, inputs, outs, steps, warmup, pipelined, stream, dev, pre=False):
+    """ms per step of a continuous stream of batches (rotating through `inputs`), N = 1, no exchange."""
+    D = dec.pipeline_depth if pipelined else 1
+
+    def go(k):
+        fr = inputs[k % len(inputs)]
+        chunks, masks = outs[k % len(outs)]
+        if pipelined:
+            dec.decode_batch_pipelined(fr.data_ptr(), fr.shape[0], chunks.data_ptr(), masks.data_ptr(), pre, 2, stream.cuda_stream)
+        else:
+            dec.decode_batch_device(fr.data_ptr(), fr.shape[0], chunks.data_ptr(), masks.data_ptr(), pre, 2, stream.cuda_stream)
+
+    assert len(outs) >= D
+    for k in range(warmup):
+        go(k)
+    if pipelined:
+        dec.pipeline_wait(stream.cuda_stream, 0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        go(warmup + k)
+    if pipelined:
+        dec.pipeline_wait(stream.cuda_stream, 0)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def stage_times(dec, frames, outs, stream, dev, reps=5, pre=False):
+    """per-kernel ms: HIP events on the launch stream, recorded inside the library (un-split chain, one launch per kernel)"""
+    acc = {}
+    dec.enable_timing(True)
+    chunks, masks = outs
+    for rep in range(reps + 1):
+        dec.decode_batch_device(frames.data_ptr(), frames.shape[0], chunks.data_ptr(), masks.data_ptr(), pre, 2, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if rep == 0:
+            continue          # the first ordinary call after the pipelined steps is not representative
+        for k, v in dec.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    dec.enable_timing(False)
+    return acc
+
+
+def extras(dec, dev, stream, n, outs, steps):
+    """N = 1 secondary rows (same process, same box, after the headline loop)."""
+    out = {}
+    synth = framegen.FrameSynth(dev)
+    # ---- BASELINE configs[2]: n frames, 99 substituted cells each (rng 5678 + frame), every RS block in its error path
+    try:
+        payload = framegen.synth_payload(n, seed=1234, device=dev)
+        tiles = framegen.inject_cell_errors(synth.cell_tiles(payload), n_errors=99, seed=5678)
+        fe = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+        for lo in range(0, n, 64):
+            synth.render(tiles[lo:lo + 64], out=fe[lo:lo + 64])
+        del tiles
+        ms_p = stream_ms(dec, [fe], outs, steps, 4, True, stream, dev)
+        ok = all(bool((m == 0xFFF).all().item()) and bool((c == payload).all().item()) for c, m in outs[:dec.pipeline_depth])
+        ms_u = stream_ms(dec, [fe], outs, max(8, steps // 4), 2, False, stream, dev)
+        st = stage_times(dec, fe, outs[0], stream, dev, reps=3)
+        out["config3_cell_errors"] = {"frames": n, "substituted_cells_per_frame": 99, "ms_per_step": round(ms_p, 4),
+                                      "frames_per_s": round(n / ms_p * 1e3, 1), "no_pipeline_ms_per_step": round(ms_u, 4),
+                                      "payload_ok": ok, "stage_ms": {k: round(v, 4) for k, v in st.items()}}
+        del fe
+    except Exception as e:   # a secondary row must never take the headline down
+        out["config3_cell_errors"] = {"error": repr(e)}
+    # ---- host-fed decode: pinned host frames in, chunks back to the host, H2D + D2H inside the timed region
+    try:
+        m = min(n, 256)
+        payload, fr = make_frames(m, dev, 4242, dec, check=False)
+        host = fr.cpu().pin_memory()
+        del fr
+        hv = host.numpy()
+        dec.decode_batch(hv[:8])
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            total, chunks, masks = dec.decode_batch(hv)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        ok = total == m * 7500 and bool((torch.from_numpy(chunks.reshape(m, -1)) == payload.cpu()).all())
+        out["host_fed"] = {"frames": m, "ms": round(best * 1e3, 3), "frames_per_s": round(m / best, 1),
+                           "pcie_GBs": round(m * modeb.FRAME_RGB_BYTES / best / 1e9, 2), "payload_ok": ok,
+                           "note": "pinned host memory -> cimbar_hip_decode_batch(host in, host out): one H2D copy + decode + D2H, synchronous"}
+        del host, hv
+    except Exception as e:
+        out["host_fed"] = {"error": repr(e)}
+    try:
+        from libcimbar_amd import extractbench
+        out.update(extractbench.run(dec, dev, stream, synth))
+    except ImportError:
+        pass
+    except Exception as e:
+        out["config5_extract"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -118,7 +231,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (BASELINE configs[1]: 1024)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4), help="2: BASELINE configs[1] (default); 4: configs[3], the sharded fountain stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one ordinary call per step instead of the pipelined entry point (kernels of different steps never overlap: "
                          "what tools/gpu_profile.sh uses so that every traced dispatch is one kernel running alone)")
@@ -141,27 +256,43 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.config == 4:
+        from libcimbar_amd import config4
+        line = config4.bench(dec, dev, rank, world, args)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     n = args.frames
-    payload, frames = make_frames(n, dev, seed=1234 + rank, dec=dec)
     # The batches form a continuous stream, so the library's pipelined entry point is used: up to D = pipeline_depth steps are in flight
     # on the context's own streams, the threshold pass of one overlapping the short kernels of the others (colour-correction carry-over
     # still in batch order). A step's outputs are consumed D-1 steps later: with N > 1 the RCCL gather of step k-D+1 is issued right
     # after step k has been enqueued. D output buffer sets (and, on rank 0, D gather destinations).
     D = 1 if args.no_pipeline else dec.pipeline_depth
     NB = max(D, 2)
+    # R distinct input batches, decoded in rotation: steps in flight at the same time never read the same frames (two threshold passes
+    # walking the same addresses a few frames apart would share lines through L2 / the Infinity Cache, which a real stream cannot)
+    R = max(dec.pipeline_depth, 2)
+    batches = [make_frames(n, dev, seed=1234 + 97 * rank + 7919 * b, dec=dec, check=(b == 0)) for b in range(R)]
+    payloads = [p for p, _ in batches]
+    inputs = [f for _, f in batches]
     outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev))
             for _ in range(NB)]
     gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev),
                  torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(NB)]
     stream = torch.cuda.current_stream(dev)
+    which = [0] * NB          # input batch last decoded into output set b
 
     def issue(b, k):
         chunks, masks = outs[b]
+        fr = inputs[k % R]
+        which[b] = k % R
         if args.no_pipeline:
-            dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
+            dec.decode_batch_device(fr.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
         else:
-            dec.decode_batch_pipelined(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
+            dec.decode_batch_pipelined(fr.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
 
     def ready(keep_newest):
         if not args.no_pipeline:
@@ -180,7 +311,6 @@ def main():
         step()
     drain()
     barrier()
-    stage_acc = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -193,31 +323,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered, both buffer sets
+    # correctness of what was just timed (outside the timed region): bit-exact payload, every chunk delivered, every buffer set
     ok = True
-    for chunks, masks in outs[:min(NB, pipe.steps)]:
-        ok = ok and bool((masks == 0xFFF).all().item()) and bool((chunks == payload).all().item())
+    for b, (chunks, masks) in enumerate(outs[:min(NB, pipe.steps)]):
+        ok = ok and bool((masks == 0xFFF).all().item()) and bool((chunks == payloads[which[b]]).all().item())
     if world > 1 and rank == 0:
-        ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payload).all().item()) \
+        last_in = (pipe.steps - 1) % R
+        ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payloads[last_in]).all().item()) \
             and bool((all_masks == 0xFFF).all().item())
     if not ok:
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
-    # per-kernel times of a few more steps: HIP events on the launch stream, recorded inside the library. With timing on,
-    # the library runs the batch un-sliced on one stream (one launch per kernel), so each figure is one kernel's duration.
-    dec.enable_timing(True)
-    reps = 5
-    chunks, masks = outs[0]
-    for rep in range(reps + 1):
-        dec.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        if rep == 0:
-            continue          # the first ordinary call after the pipelined steps is not representative
-        for k, v in dec.stage_times().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v / reps
-
+    line = None
     if rank == 0:
         frames_per_s = world * n * args.steps / elapsed
+        stage_acc = stage_times(dec, inputs[0], outs[0], stream, dev)
         dom = max(stage_acc, key=stage_acc.get)
         dom_ms = stage_acc[dom]
         achieved = ALGO_BYTES_PER_FRAME * n / (dom_ms * 1e-3) / 1e9
@@ -226,8 +346,10 @@ def main():
             "metric": "decoded cimbar frames/s (1024x1024 mode-B)", "value": round(frames_per_s, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"batch of {n} synthetic clean mode-B frames per GPU, device-resident, bit-exact vs encoded payload",
-                       "frames_per_gpu_per_step": n, "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
+            "config": {"workload": f"batch of {n} synthetic clean mode-B frames per GPU, device-resident, {R} distinct batches decoded in "
+                                   "rotation, bit-exact vs encoded payload",
+                       "frames_per_gpu_per_step": n, "distinct_input_batches": R,
+                       "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
                                       ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": ALGO_BYTES_PER_FRAME * n,
@@ -235,9 +357,25 @@ def main():
                          "whole_path_frac": round(frames_per_s / world * ALGO_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sample = frames[:min(n, 64)].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample)
+    if world == 1:
+        if not args.no_pipeline:
+            ms_u = stream_ms(dec, inputs, outs, args.steps, min(args.warmup, 4), False, stream, dev)
+            line["no_pipeline"] = {"ms_per_step": round(ms_u, 4), "frames_per_s": round(n / ms_u * 1e3, 1),
+                                   "whole_path_frac": round(n / ms_u * 1e3 * ALGO_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5)}
+        if not args.no_cpu_baseline:
+            k = min(n, 64)
+            chunks, masks = outs[0]
+            dec.reset_ccm()
+            dec.decode_batch_device(inputs[0].data_ptr(), k, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            line["cpu_baseline"] = cpu_baseline(inputs[0][:k].cpu().numpy(), chunks[:k].cpu().numpy())
+            line["payload_sha_match"] = line["cpu_baseline"]["payload_sha_match"]
+        if not args.no_extras:
+            del batches
+            inputs[1:] = []
+            torch.cuda.empty_cache()
+            line["extra"] = extras(dec, dev, stream, n, outs, max(20, args.steps // 4))
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

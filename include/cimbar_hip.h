@@ -53,6 +53,10 @@ void cimbar_hip_destroy(cimbar_hip_ctx* ctx);
 /* cimbard_get_bufsize(): bytes of chunk space one frame needs (12 * 625) */
 int cimbar_hip_bufsize(void);
 
+/* The 16 symbol-tile hashes as cimbar_hip_create computes them from the embedded tile bitmaps -- what CimbDecoder's constructor does
+ * (CimbDecoder.cpp:58-66,87-99: getTile -> average_hash). Host-only arithmetic (works without a device); returns 16. */
+int cimbar_hip_tile_hashes(uint64_t out16[16]);
+
 /* human-readable text of the last failure on this context (never NULL) */
 const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
 
@@ -126,7 +130,7 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
  * 1080p capture instead of 6 MB), and its four corners come back for the warp, whose output can stay in device memory for
  * cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated, see DESIGN.md.
  *   cimbar_hip_scan_preprocess : n captures -> n * width * height bytes (0 / 255) = Scanner::preprocess_image(img, fast = true);
- *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Short side above 3000 px: EDIM.
+ *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Short side >= 2500 px (9x9 blur): EDIM.
  *   cimbar_hip_deskew_batch    : corners = n * 8 floats in HOST memory, per capture top-left, top-right, bottom-left, bottom-right (x, y)
  *                                exactly as Corners::all() returns them (Corners.h:45-53); frames = n * 1024*1024*3 bytes = what
  *                                Deskewer(0, {1024,1024}, 30).deskew(img, corners) returns.

@@ -52,12 +52,10 @@ constexpr size_t FRAME_RGB = (size_t)IMG * IMG * 3;
 constexpr int ANCHOR = 30;
 constexpr int HEAP_CAP = 12 * NCELLS + 64;            // <= 12 offers per decoded cell + 8 seeds
 
-// the 16 tile hashes (CimbDecoder.cpp:87-99 computes them from bitmaps.h; checked against the reference build in tests)
-__constant__ uint64_t c_tile[16] = {
-	0xfffefcf8f0e0c080ULL, 0x80c0e0f0f8fcfeffULL, 0xff7f3f1f0f070301ULL, 0x0103070f1f3f7fffULL,
-	0x181818ffff181818ULL, 0x66e7e70000e7e766ULL, 0x3c7ee7c3c3e77e3cULL, 0x18183c3c7e7effffULL,
-	0xc0f0fcfffffcf0c0ULL, 0xfffcf00000f0fcffULL, 0xff3f0f00000f3fffULL, 0xe7e7e7e7c3c38181ULL,
-	0x8181c3c3e7e7e7e7ULL, 0x0000c3e77e3c1800ULL, 0x0c1c387070381c0cULL, 0x1e1e38381c1c7878ULL};
+// the 16 tile hashes and the exact-match slot table of k_symbols: computed by cimbar_hip_create from the tile bitmaps the way
+// CimbDecoder's constructor does (CimbDecoder.cpp:58-66,87-99 -> Common.cpp:150-171 getTile -> average_hash.h:19-39), see
+// build_tile_hashes() in host.hip.inc
+__constant__ uint64_t c_tile[16];
 
 // Common.cpp:21-31 getColor4 (colour_mode 1)
 __constant__ int c_palette[4][3] = {{0, 255, 0}, {0, 255, 255}, {255, 255, 0}, {255, 0, 255}};

@@ -25,7 +25,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
-    "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch",
+    "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
 )
 
 
@@ -53,6 +53,8 @@ def load_library(path=None):
     lib.cimbar_hip_destroy.restype = None
     lib.cimbar_hip_bufsize.argtypes = []
     lib.cimbar_hip_bufsize.restype = i32
+    lib.cimbar_hip_tile_hashes.argtypes = [vp]
+    lib.cimbar_hip_tile_hashes.restype = i32
     lib.cimbar_hip_last_error.argtypes = [vp]
     lib.cimbar_hip_last_error.restype = ctypes.c_char_p
     lib.cimbar_hip_decode_frame.argtypes = [vp, vp, u32, u32, sz, i32, i32, vp, ctypes.POINTER(ctypes.c_uint32)]
@@ -88,6 +90,13 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def tile_hashes():
+    """the 16 tile hashes the library computes at create time (host arithmetic, no device needed)"""
+    out = np.zeros(16, dtype=np.uint64)
+    load_library().cimbar_hip_tile_hashes(out.ctypes.data)
+    return out
 
 
 _ERR = {-1: "EINVAL", -2: "EDIM", -3: "ENODEVICE", -4: "EHIP", -5: "ENOMEM"}

@@ -23,6 +23,7 @@
 #include "extractor/Scanner.h"
 #include "fountain/fountain_decoder_sink.h"
 #include "fountain/fountain_encoder_stream.h"
+#include "compression/zstd_decompressor.h"
 
 #include <cstdint>
 #include <cstring>
@@ -171,6 +172,39 @@ int ref_encode_fountain(const uint8_t* data, unsigned size, int encode_id, unsig
 		for (int y = 0; y < frame->rows; ++y) std::memcpy(dst + (size_t)y * frame->cols * 3, frame->ptr<uchar>(y), (size_t)frame->cols * 3);
 	}
 	return (int)nframes;
+}
+
+// BASELINE configs[0] as `./cimbar --encode` makes it (cimbar.cpp:106-121 -> EncoderPlus.h:45-98): zstd at `compression` with the
+// file's basename in a skippable header frame, encode id as given (the CLI uses 109), minus the will_it_scan filter
+int ref_encode_fountain_z(const uint8_t* data, unsigned size, int encode_id, int compression, const char* basename, unsigned first_frame,
+                          unsigned nframes, uint8_t* out_rgb)
+{
+	std::stringstream ss(std::string((const char*)data, size));
+	Encoder enc;
+	enc.set_encode_id((uint8_t)encode_id);
+	fountain_encoder_stream::ptr fes = enc.create_fountain_encoder(ss, basename ? basename : "", compression);
+	if (!fes) return -1;
+	size_t fsz = (size_t)cimbar::Config::image_size_x() * cimbar::Config::image_size_y() * 3;
+	for (unsigned f = 0; f < first_frame + nframes; ++f)
+	{
+		auto frame = enc.encode_next(*fes);
+		if (!frame) return (int)f;
+		if (f < first_frame) continue;
+		uint8_t* dst = out_rgb + (size_t)(f - first_frame) * fsz;
+		for (int y = 0; y < frame->rows; ++y) std::memcpy(dst + (size_t)y * frame->cols * 3, frame->ptr<uchar>(y), (size_t)frame->cols * 3);
+	}
+	return (int)nframes;
+}
+
+// what the decode side of the CLI does with a recovered fountain file (cimbar.cpp: decompress_on_store -> zstd_decompressor)
+int ref_zstd_decompress(const uint8_t* in, unsigned n, uint8_t* out, unsigned cap)
+{
+	cimbar::zstd_decompressor<std::stringstream> d;
+	if (!d.write((const char*)in, n)) return -1;
+	const std::string s = d.str();
+	if (s.size() > cap) return -2;
+	std::memcpy(out, s.data(), s.size());
+	return (int)s.size();
 }
 
 // the fountain chunk stream itself (what the frames above carry), 625 bytes per chunk

@@ -58,3 +58,21 @@ def test_cpp_adapter_and_its_test_program_compile():
     hdr = os.path.join(ROOT, "include", "cimbar_hip.h")
     res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr      # the public header is plain C
+
+
+def test_tile_hashes_computed_by_the_library_match_the_reference_build(ref):
+    """row a19: the library derives its 16 tile hashes at create time from embedded bitmaps (CimbDecoder.cpp:87-99); they must be the
+    ones the reference's CimbDecoder constructor computes (ref_tile_hashes) and the golden table in libcimbar_amd/modeb.py"""
+    import numpy as np
+    from libcimbar_amd import modeb
+    from oracle import pyref
+    mine = decoder.tile_hashes()
+    assert (mine == modeb.TILE_HASHES).all()
+    want = np.zeros(16, np.uint64)
+    assert ref.ref_tile_hashes(pyref.P(want)) == 16
+    assert (mine == want).all()
+
+
+def test_tile_hashes_match_the_golden_table():
+    from libcimbar_amd import modeb
+    assert (decoder.tile_hashes() == modeb.TILE_HASHES).all()

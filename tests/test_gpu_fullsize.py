@@ -38,7 +38,7 @@ def test_config3_cell_errors_are_all_corrected(hip_decoder):
     # BASELINE configs[2]: 0.8 % of the cells (99) replaced by a different valid tile -> RS corrects every block
     dev = torch.device("cuda", 0)
     synth = framegen.FrameSynth(dev)
-    n = 256
+    n = 1024   # BASELINE configs[2] at full size
     payload = framegen.synth_payload(n, seed=1234, device=dev)
     tiles = framegen.inject_cell_errors(synth.cell_tiles(payload), n_errors=99, seed=5678)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)

@@ -104,3 +104,49 @@ def test_pipeline_keeps_order_over_many_batches(synth):
         assert (m.cpu().numpy().astype(np.uint32) == want[j][2]).all(), j
         assert (c.cpu().numpy().reshape(3, 12, 625) == want[j][1]).all(), j
     dec.close()
+
+
+def test_small_pipelined_batches_then_a_larger_host_output_batch(synth):
+    """the host-output staging buffers are shared by every scratch set: pipelined calls with small n on the other sets must not
+    shrink what a later, larger host-output batch on the first set writes into (round-1 advisor finding)"""
+    dev = torch.device("cuda", 0)
+    payload, clean = F.clean_frames(synth, 8, seed=99)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    dec = D.HipDecoder(0)
+    total, chunks, masks = dec.decode_batch(clean)                       # set 0: capacity 8, staging 8 frames
+    assert total == 8 * 7500
+    t = torch.from_numpy(np.ascontiguousarray(clean[:2])).to(dev)
+    c = [torch.zeros((2, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev) for _ in range(dec.pipeline_depth)]
+    m = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(dec.pipeline_depth)]
+    for k in range(dec.pipeline_depth):                                  # rotates through every set and back to set 0
+        dec.decode_batch_pipelined(t.data_ptr(), 2, c[k].data_ptr(), m[k].data_ptr(), False, 2, st)
+    dec.pipeline_wait(st)
+    torch.cuda.synchronize()
+    total, chunks, masks = dec.decode_batch(clean)
+    assert total == 8 * 7500 and (masks == 0xFFF).all() and (chunks.reshape(8, -1) == payload).all()
+    rc, data, ok = dec.decode_plain_batch(clean)
+    assert rc == 8 * 7500 and ok.all() and (data == payload).all()
+    dec.close()
+
+
+def test_batch_without_any_matrix_takes_the_carried_one(synth):
+    """a long batch whose frames yield no matrix of their own (blank frames) resolves the matrix in force by the workgroup-wide
+    backward probe of k_colors: every frame must use the carried matrix, and the carry must survive the batch"""
+    dev = torch.device("cuda", 0)
+    payload, clean = F.clean_frames(synth, 1, seed=3)
+    dec = D.HipDecoder(0)
+    dec.decode_batch(clean)
+    active, carried = dec.get_ccm()
+    assert active
+    n = 700
+    blank = torch.zeros((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+    blank[n - 1] = torch.from_numpy(clean[0]).to(dev)
+    c = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    m = torch.zeros((n,), dtype=torch.int32, device=dev)
+    dec.decode_batch_device(blank.data_ptr(), n, c.data_ptr(), m.data_ptr(), False, 2, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    used = dec.tap(D.TAP_CCM, n)
+    assert (used[:n - 1, :9].tobytes() == np.tile(carried.reshape(1, 9), (n - 1, 1)).astype(np.float32).tobytes())
+    assert (used[:n - 1, 9] != 0).all()
+    assert int(m[n - 1].item()) == 0xFFF and (c[n - 1].cpu().numpy() == payload[0]).all()
+    dec.close()

@@ -8,11 +8,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel-level evidence is taken with --no-pipeline: every dispatch then runs alone, which is also how bench.py itself measures
 # stage_ms / roofline (its timing reps are ordinary calls); the default (pipelined) command is traced as well for the record
-BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline"
+BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-pipeline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 grep '"metric"' $OUT/trace.log | tail -1 > ${OUT}_bench_under_trace.json
 mkdir -p $OUT/tracep
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracep -o trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/tracep.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracep -o trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/tracep.log 2>&1
 grep '"metric"' $OUT/tracep.log | tail -1 > ${OUT}_bench_under_trace_pipelined.json
 python - "$OUT/tracep" "${OUT}_kernel_stats_pipelined.csv" <<'PY'
 import csv, glob, os, sys
