@@ -148,7 +148,8 @@ enum {
 	CIMBAR_HIP_TAP_DRIFT = 3,      /* n * 12400 * 2 int8: accumulated (dx,dy) at which each cell's colour is read */
 	CIMBAR_HIP_TAP_RS_OK = 4,      /* n * 60 bytes    : 1 = libcorrect-equivalent decode returned > 0, per RS block */
 	CIMBAR_HIP_TAP_FLOOD = 5,      /* n bytes         : 1 = frame needed the exact flood-order pass */
-	CIMBAR_HIP_TAP_CCM = 6         /* n * 10 floats   : 3x3 matrix used for the colour pass + active flag */
+	CIMBAR_HIP_TAP_CCM = 6,        /* n * 10 floats   : 3x3 matrix used for the colour pass + active flag */
+	CIMBAR_HIP_TAP_FLOOD_PATH = 7  /* n bytes         : 0 = parallel pass was exact, 1 = exact flood replay, 2 = certified batch flood */
 };
 int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes);
 

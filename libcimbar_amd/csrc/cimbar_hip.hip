@@ -10,6 +10,7 @@
 //   K1 k_threshold      RGB -> gray -> (sharpen) -> 5x5|7x7 box-mean threshold -> bitplane   [HBM-read bound]
 //   K2 k_symbols        every cell at drift (0,0): 10x10 bit window -> 5|9 shifted 8x8 hashes -> popcount match;
 //                       flags the frame if any cell prefers a shifted window (order then matters -> K2b)
+//   K2c k_flood_wave    batch-parallel flood for frames whose result provably does not depend on the reference's tie order
 //   K2b k_flood         exact emulation of the reference's priority-flood order + drift, one wavefront per flagged frame,
 //                       heap and per-cell state in LDS
 //   K3 k_rs             de-interleave + RS(155,125) decode, one block per wavefront (symbols: 40 blocks)
@@ -78,6 +79,7 @@ struct Tables {
 #include "k1_threshold.hip.inc"
 #include "k2_symbols.hip.inc"
 #include "k2b_flood.hip.inc"
+#include "k2c_floodwave.hip.inc"
 #include "k3_rs.hip.inc"
 #include "k4_frame.hip.inc"
 #include "encode.hip.inc"

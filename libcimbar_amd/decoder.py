@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM = range(7)
+TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM, TAP_FLOOD_PATH = range(8)
 
 # every symbol include/cimbar_hip.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
 EXPORTS = (
@@ -285,7 +285,7 @@ class HipDecoder:
         shapes = {
             TAP_BITPLANE: ((n, modeb.IMG * modeb.IMG // 8), np.uint8), TAP_SYMBOLS: ((n, modeb.NCELLS), np.uint8),
             TAP_COLORS: ((n, modeb.NCELLS), np.uint8), TAP_DRIFT: ((n, modeb.NCELLS, 2), np.int8),
-            TAP_RS_OK: ((n, 60), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32),
+            TAP_RS_OK: ((n, 60), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8),
         }
         shape, dt = shapes[what]
         out = np.zeros(shape, dtype=dt)

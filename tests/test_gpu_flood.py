@@ -15,6 +15,19 @@ from tests import frames as F
 pytestmark = pytest.mark.gpu
 
 
+def exact_decoder(lib_path=None):
+    """a decoder whose flagged frames ALL take the exact replay (k_flood): the batch-parallel pass in front of it is switched off"""
+    old = os.environ.get("CIMBAR_HIP_FLOOD_WAVE")
+    os.environ["CIMBAR_HIP_FLOOD_WAVE"] = "0"
+    try:
+        return D.HipDecoder(0, lib_path=lib_path)
+    finally:
+        if old is None:
+            del os.environ["CIMBAR_HIP_FLOOD_WAVE"]
+        else:
+            os.environ["CIMBAR_HIP_FLOOD_WAVE"] = old
+
+
 def flood_frames(synth):
     payload, frames = F.clean_frames(synth, 4, seed=91)
     rng = np.random.default_rng(3)
@@ -44,14 +57,79 @@ def check(dec, frames, names):
         assert masks[k] == wmask and (chunks[k] == wchunks).all(), names[k]
 
 
-def test_flood_pass_matches_oracle(hip_decoder, synth):
+def test_flood_pass_matches_oracle(synth):
+    frames, names = flood_frames(synth)
+    dec = exact_decoder()
+    check(dec, frames, names)
+    assert (dec.tap(D.TAP_FLOOD_PATH, len(frames)) == 1).all()
+
+
+def test_flood_through_the_default_path_matches_oracle(hip_decoder, synth):
+    """the same frames through the library as shipped: the batch-parallel flood (k_flood_wave) takes what it can certify, the exact
+    replay the rest -- results must not depend on which one ran"""
     frames, names = flood_frames(synth)
     check(hip_decoder, frames, names)
+    path = hip_decoder.tap(D.TAP_FLOOD_PATH, len(frames))
+    assert path[0] == 2, "a clean, rigidly shifted frame is the textbook case for the batch-parallel flood"
+    assert path[3] == 1, "pure noise cannot be certified"
+
+
+def wave_frames(synth):
+    payload, fr = F.clean_frames(synth, 6, seed=191)
+    return [
+        F.shift(fr[0], 2, 1), F.shift(fr[1], 1, 0), F.shift(fr[2], -1, -1), F.shift(fr[3], 0, 3),
+        F.blank_region(F.shift(fr[4], 1, 1), 300, 420, 0, 1024),              # a wiped band: the wave has to go around / through it
+        F.blank_region(fr[5], 60, 500, 60, 700),                              # unshifted, a wiped block: flagged by its garbage cells
+        F.blank_region(F.shift(fr[0], -2, 1), 0, 1024, 0, 560, value=255),    # half the frame gone
+        F.add_noise(F.shift(fr[1], 1, 2), 12, 5),                             # light noise on a shift
+    ], ["shift+2+1", "shift+1+0", "shift-1-1", "shift0+3", "shift+band", "block", "shift+half", "shift+noise12"]
+
+
+def test_batch_parallel_flood_matches_oracle_and_certifies_clean_shifts(hip_decoder, synth):
+    frames, names = wave_frames(synth)
+    check(hip_decoder, frames, names)
+    path = hip_decoder.tap(D.TAP_FLOOD_PATH, len(frames))
+    assert (path[:4] == 2).all(), f"clean rigid shifts must certify: {path}"
+    assert (path != 0).all()
+
+
+def test_batch_parallel_flood_and_exact_replay_agree(hip_decoder, synth):
+    """every frame of a larger, mixed batch: default path vs exact replay, cell by cell (no oracle: this is GPU vs GPU at a batch size the
+    oracle would take minutes for)"""
+    payload, fr = F.clean_frames(synth, 8, seed=404)
+    g = np.random.default_rng(8)
+    frames = []
+    for k in range(48):
+        f = F.shift(fr[k % 8], int(g.integers(-3, 4)), int(g.integers(-3, 4)))
+        if k % 3 == 1:
+            y0, x0 = int(g.integers(0, 800)), int(g.integers(0, 800))
+            f = F.blank_region(f, y0, y0 + int(g.integers(20, 300)), x0, x0 + int(g.integers(20, 300)), value=int(g.integers(0, 256)))
+        if k % 3 == 2:
+            f = F.add_noise(f, int(g.integers(4, 60)), k)
+        frames.append(f)
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    ex = exact_decoder()
+    outs = []
+    for dec in (hip_decoder, ex):
+        dec.reset_ccm()
+        total, chunks, masks = dec.decode_batch(frames)
+        outs.append((chunks.copy(), masks.copy(), dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_COLORS, n), dec.tap(D.TAP_FLOOD_PATH, n)))
+    a, b = outs
+    assert (b[5] <= 1).all()
+    flagged = a[5] != 0
+    assert ((a[5] != 0) == (b[5] != 0)).all()
+    for k in range(n):
+        assert (a[2][k] == b[2][k]).all(), f"frame {k} (path {a[5][k]}): symbols differ"
+        if flagged[k]:
+            assert (a[3][k] == b[3][k]).all(), f"frame {k} (path {a[5][k]}): drift differs"
+        assert (a[4][k] == b[4][k]).all() and a[1][k] == b[1][k] and (a[0][k] == b[0][k]).all(), k
+    assert (a[5] == 2).sum() >= 8, f"too few frames certified: {a[5]}"
 
 
 def test_flood_pass_with_the_heap_spilling_to_global_memory(synth):
     assert os.path.exists(hipbuild.OUT_SPILLTEST), "build it with `python -m libcimbar_amd.build` (or __graft_entry__.build())"
-    dec = D.HipDecoder(0, lib_path=hipbuild.OUT_SPILLTEST)
+    dec = exact_decoder(lib_path=hipbuild.OUT_SPILLTEST)
     frames, names = flood_frames(synth)
     check(dec, frames, names)
 
@@ -73,7 +151,7 @@ def test_split_batch_floods_with_spilling_heaps(synth):
     import torch
     from libcimbar_amd import framegen
     dev = torch.device("cuda", 0)
-    dec = D.HipDecoder(0, lib_path=hipbuild.OUT_SPILLTEST)
+    dec = exact_decoder(lib_path=hipbuild.OUT_SPILLTEST)
     n = 160
     payload = framegen.synth_payload(n, seed=11, device=dev)
     frames = torch.roll(framegen.FrameSynth(dev).frames_from_payload(payload), shifts=(1, 2), dims=(1, 2)).contiguous()

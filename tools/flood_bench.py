@@ -20,4 +20,5 @@ for n in (1, 16, 256, 1024):
     t = dec.stage_times()
     ok = bool((chunks == payload).all().item()) and bool((masks == 0xFFF).all().item())
     flagged = int(dec.tap(5, n).sum())
-    print(f"n={n} flagged={flagged} payload_ok={ok} flood={t['flood']:.2f} ms ({t['flood']/n*1e3:.1f} us/frame, {n/t['flood']*1e3:.0f} frames/s) total={sum(t.values()):.2f} ms")
+    path = dec.tap(7, n)
+    print(f"n={n} flagged={flagged} exact={int((path == 1).sum())} batch={int((path == 2).sum())} payload_ok={ok} flood={t['flood']:.2f} ms ({t['flood']/n*1e3:.1f} us/frame, {n/t['flood']*1e3:.0f} frames/s) total={sum(t.values()):.2f} ms")
