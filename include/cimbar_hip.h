@@ -140,6 +140,26 @@ int cimbar_hip_scan_preprocess(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned
 int cimbar_hip_deskew_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, int n, int rgb_mem,
                             const float* corners, uint8_t* frames, int out_mem, void* hip_stream);
 
+/* Extractor::extract (src/lib/extractor/Extractor.h:29-45) for n captures, entirely on the device: Scanner (image preparation AND the
+ * anchor search: Scanner.h:277-405, Scanner.cpp:52-202, ScanState.h:21-104) -> Corners (Corners.h:45-73) -> Deskewer::deskew.
+ *   status  : n ints, Extractor::FAILURE 0 / SUCCESS 1 / NEEDS_SHARPEN 2 (Extractor.h:18-20); -1 = one of the search's fixed-size work
+ *             lists overflowed (hundreds of anchor-like patterns on one scan line), treated as a failure
+ *   corners : n * 8 floats, Corners::all() (top-left, top-right, bottom-left, bottom-right; x, y); may be NULL. Unset where status <= 0
+ *   frames  : n * 1024*1024*3 bytes, black where status <= 0
+ * status / corners / frames share out_mem. Buffers, stream and errors as for cimbar_hip_decode_batch. */
+int cimbar_hip_extract_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, int n, int rgb_mem, uint8_t* frames,
+                             int* status, float* corners, int out_mem, void* hip_stream);
+
+/* cimbard_scan_extract_decode (src/lib/cimbar_js/cimbar_recv_js.cpp:148-189) / the body of cimbar.cpp's decode loop (:124-162) for n
+ * captures: extract, then Decoder::decode_fountain on what came out, the deskewed frames never leaving the device.
+ *   preprocess : 1 sharpen every frame, 0 none, anything else ("-1 == guess", cimbar.cpp:190) where the extractor said NEEDS_SHARPEN
+ *   chunks / masks : as for cimbar_hip_decode_batch; a capture whose extraction failed delivers nothing (mask 0, slots zeroed)
+ *   status     : as for cimbar_hip_extract_batch; may be NULL
+ * Host outputs: synchronises and returns the total good bytes; device outputs: enqueues and returns 0. */
+int64_t cimbar_hip_scan_extract_decode_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, int n, int rgb_mem,
+                                             int preprocess, int color_correction, uint8_t* chunks, uint32_t* masks, int* status, int out_mem,
+                                             void* hip_stream);
+
 /* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
 enum {
 	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */

@@ -84,6 +84,7 @@ struct Tables {
 #include "k4_frame.hip.inc"
 #include "encode.hip.inc"
 #include "extract.hip.inc"
+#include "scan.hip.inc"
 
 }  // namespace
 

@@ -26,6 +26,7 @@ EXPORTS = (
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
+    "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch",
 )
 
 
@@ -73,6 +74,10 @@ def load_library(path=None):
     lib.cimbar_hip_scan_preprocess.restype = i32
     lib.cimbar_hip_deskew_batch.argtypes = [vp, vp, u32, u32, i32, i32, vp, vp, i32, vp]
     lib.cimbar_hip_deskew_batch.restype = i32
+    lib.cimbar_hip_extract_batch.argtypes = [vp, vp, u32, u32, i32, i32, vp, vp, vp, i32, vp]
+    lib.cimbar_hip_extract_batch.restype = i32
+    lib.cimbar_hip_scan_extract_decode_batch.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.cimbar_hip_scan_extract_decode_batch.restype = i64
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -229,6 +234,37 @@ class HipDecoder:
         self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(n), MEM_DEVICE,
                                                       corners.ctypes.data, ctypes.c_void_p(frames_ptr), MEM_DEVICE,
                                                       ctypes.c_void_p(stream) if stream else None), "cimbar_hip_deskew_batch(device)")
+
+    def extract_batch(self, captures):
+        """Extractor::extract for captures (n,h,w,3) uint8 numpy -> (status (n,) int32, corners (n,8) float32, frames (n,1024,1024,3))"""
+        captures = np.ascontiguousarray(captures, dtype=np.uint8)
+        n, h, w = captures.shape[:3]
+        frames = np.zeros((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        corners = np.zeros((n, 8), dtype=np.float32)
+        self._check(self._lib.cimbar_hip_extract_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, frames.ctypes.data, status.ctypes.data,
+                                                       corners.ctypes.data, MEM_HOST, None), "cimbar_hip_extract_batch")
+        return status, corners, frames
+
+    def scan_extract_decode_batch(self, captures, preprocess=-1, color_correction=2):
+        """cimbard_scan_extract_decode for captures (n,h,w,3) uint8 numpy -> (good_bytes, chunks (n,12,625), masks (n,), status (n,))"""
+        captures = np.ascontiguousarray(captures, dtype=np.uint8)
+        n, h, w = captures.shape[:3]
+        chunks = np.zeros((n, modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        masks = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.int32)
+        rc = self._check(self._lib.cimbar_hip_scan_extract_decode_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, int(preprocess),
+                                                                         int(color_correction), chunks.ctypes.data, masks.ctypes.data,
+                                                                         status.ctypes.data, MEM_HOST, None), "cimbar_hip_scan_extract_decode_batch")
+        return int(rc), chunks, masks, status
+
+    def scan_extract_decode_device(self, captures_ptr, w, h, n, chunks_ptr, masks_ptr, status_ptr=None, preprocess=-1, color_correction=2, stream=None):
+        """device captures in, device chunks / masks / status out; asynchronous on `stream`"""
+        self._check(self._lib.cimbar_hip_scan_extract_decode_batch(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(n), MEM_DEVICE,
+                                                                    int(preprocess), int(color_correction), ctypes.c_void_p(chunks_ptr),
+                                                                    ctypes.c_void_p(masks_ptr), ctypes.c_void_p(status_ptr) if status_ptr else None,
+                                                                    MEM_DEVICE, ctypes.c_void_p(stream) if stream else None),
+                    "cimbar_hip_scan_extract_decode_batch(device)")
 
     # ------------------------------------------------------------------ the reference's operator surface
     def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):

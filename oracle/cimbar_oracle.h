@@ -84,6 +84,11 @@ int co_warp_perspective(const uint8_t* rgb, int sw, int sh, const double* m9, ui
 /* Deskewer::deskew for mode B from the four corners (top-left, top-right, bottom-left, bottom-right; x, y) */
 int co_deskew(const uint8_t* rgb, int sw, int sh, const float* corners8, uint8_t* out1024);
 
+/* Scanner::scan (Scanner.cpp:183-202) on the 0/255 image: up to 4 anchors {x, xmax, y, ymax} (top-left, top-right, bottom-left, bottom-right); returns the count */
+int co_scan_anchors(const uint8_t* binary, int w, int h, int32_t* anchors16);
+/* Extractor::extract (Extractor.h:29-45): 0 failure / 1 success / 2 needs sharpen; corners8 = Corners::all(); out = deskewed 1024x1024 RGB8 */
+int co_extract(const uint8_t* rgb, int w, int h, uint8_t* out1024, float* corners8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,314 @@ int co_deskew(const uint8_t* rgb, int sw, int sh, const float* corners8, uint8_t
 	co_perspective_transform(corners8, dst8, m9);
 	return co_warp_perspective(rgb, sw, sh, m9, out1024, 1024, 1024);
 }
+
+/* ------------------------------------------------------------------------------------------------ anchor search
+ * Scanner::scan (src/lib/extractor/Scanner.cpp:183-202) on the 0/255 image of co_scan_preprocess, restated:
+ *   ScanState                       ScanState.h:21-104   run-length state machine looking for active:inactive runs 1:1:4:1:1 (limits 3..6,
+ *                                                        "114") resp. 1:2:2:2:1 ("122", the smaller bottom-right anchor)
+ *   scan_horizontal/vertical/diagonal Scanner.h:167-275
+ *   t1 rows -> t2 column -> t3 diagonal -> t4 confirm    Scanner.h:277-405
+ *   deduplication while scanning (on_t1_scan)            Scanner.h:391-405, Anchor::is_mergeable Anchor.h:87-95
+ *   filter_candidates / sort_top_to_bottom / add_bottom_right_corner   Scanner.cpp:79-181
+ * dark mode only (test_pixel: pixel > 127, Scanner.cpp:52-59). */
+typedef struct { int x, xmax, y, ymax; } anchor_t;
+
+static int a_xavg(const anchor_t* a) { return (a->x + a->xmax) / 2; }
+static int a_yavg(const anchor_t* a) { return (a->y + a->ymax) / 2; }
+static int a_xrange(const anchor_t* a) { return abs(a->x - a->xmax) / 2; }
+static int a_yrange(const anchor_t* a) { return abs(a->y - a->ymax) / 2; }
+static int a_max_range(const anchor_t* a) { int p = abs(a->x - a->xmax), q = abs(a->y - a->ymax); return p > q ? p : q; }
+static unsigned long long a_size(const anchor_t* a)
+{
+	return (unsigned long long)(pow((double)(a->x - a->xmax), 2) + pow((double)(a->y - a->ymax), 2));   /* Anchor.h:77-80 */
+}
+static void a_merge(anchor_t* a, const anchor_t* o)
+{
+	if (o->x < a->x) a->x = o->x;
+	if (o->xmax > a->xmax) a->xmax = o->xmax;
+	if (o->y < a->y) a->y = o->y;
+	if (o->ymax > a->ymax) a->ymax = o->ymax;
+}
+/* Anchor.h:87-95 (a division by a zero max_range cannot happen for anchors the scans produce: every run pattern is >= 5 px long) */
+static int a_mergeable(const anchor_t* a, const anchor_t* rhs, int max_distance)
+{
+	if (abs(a_xavg(a) - a_xavg(rhs)) > max_distance || abs(a_yavg(a) - a_yavg(rhs)) > max_distance) return 0;
+	const int mr = a_max_range(a);
+	if (mr == 0) return 0;
+	const int ratio = a_max_range(rhs) * 10 / mr;
+	return ratio > 6 && ratio < 17;
+}
+
+typedef struct { int state; int tally[8]; int nt; const float (*limits)[2]; } scan_state;
+static const float LIM_114[6][2] = {{0, 0}, {3.0f, 6.0f}, {3.0f, 6.0f}, {0, 0}, {3.0f, 6.0f}, {3.0f, 6.0f}};
+static const float LIM_122[6][2] = {{0, 0}, {1.0f, 3.0f}, {0.5f, 1.5f}, {0, 0}, {0.5f, 1.5f}, {1.0f, 3.0f}};
+static void ss_init(scan_state* s, int kind) { s->state = 0; s->nt = 1; s->tally[0] = 0; s->limits = kind == 114 ? LIM_114 : LIM_122; }
+/* ScanState::process, ScanState.h:21-60 (+ evaluate_state :70-97, pop_state :63-68) */
+static int ss_process(scan_state* s, int active)
+{
+	const int even = s->state == 0 || s->state == 2 || s->state == 4;
+	const int odd = s->state == 1 || s->state == 3 || s->state == 5;
+	if ((even && active) || (odd && !active)) {
+		s->state += 1;
+		s->tally[s->nt++] = 1;
+		if (s->state == 6) {
+			int res = -1, okp = 1;
+			for (int i = 1; i <= 5; ++i) if (s->tally[i] == 0) okp = 0;
+			if (okp) {
+				const float center = (float)s->tally[3];
+				for (int i = 1; i <= 5 && okp; ++i) {
+					if (i == 3) continue;
+					const float ratio_min = center / (float)(s->tally[i] + 1);
+					const float ratio_max = center / (float)(s->tally[i] - 1 > 1 ? s->tally[i] - 1 : 1);
+					if (ratio_max < s->limits[i][0] || ratio_min > s->limits[i][1]) okp = 0;
+				}
+				if (okp) { res = 0; for (int i = 1; i <= 5; ++i) res += s->tally[i]; }
+			}
+			s->state -= 2;
+			for (int i = 0; i + 2 < s->nt; ++i) s->tally[i] = s->tally[i + 2];
+			s->nt -= 2;
+			return res;
+		}
+		return -1;
+	}
+	if (odd && active) s->tally[s->nt - 1] += 1;
+	if (!active && (s->state == 2 || s->state == 4)) s->tally[s->nt - 1] += 1;
+	return -1;
+}
+
+typedef struct { const uint8_t* img; int w, h, skip, cutoff; } scanner_t;
+typedef struct { anchor_t* v; int n, cap; } alist;
+static __thread int g_dbg_max_list = 0;   /* longest list any scan built during the last co_scan_anchors (sizes the device kernel's fixed lists) */
+int co_scan_debug_max_list(void) { return g_dbg_max_list; }
+static void al_push(alist* l, anchor_t a)
+{
+	if (l->n + 1 > g_dbg_max_list) g_dbg_max_list = l->n + 1;
+	if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 64; l->v = (anchor_t*)realloc(l->v, sizeof(anchor_t) * (size_t)l->cap); }
+	l->v[l->n++] = a;
+}
+static int test_pixel(const scanner_t* sc, int x, int y)
+{
+	if (x < 0 || y < 0 || x >= sc->w || y >= sc->h) return 0;   /* the reference reads out of bounds here (confirm scans next to the image border) */
+	return sc->img[(size_t)y * sc->w + x] > 127;
+}
+
+/* Scanner.h:167-197 */
+static int scan_horizontal(const scanner_t* sc, int kind, alist* pts, int y, int xstart, int xend)
+{
+	if (xstart < 0) xstart = 0;
+	if (xend < 0 || xend > sc->w) xend = sc->w;
+	const int init = pts->n;
+	scan_state st;
+	ss_init(&st, kind);
+	for (int x = xstart; x < xend; ++x) {
+		const int res = ss_process(&st, test_pixel(sc, x, y));
+		if (res > 0) { anchor_t a = {x - res, x - 1, y, y}; al_push(pts, a); }
+	}
+	const int res = ss_process(&st, 0);
+	if (res > 0) { anchor_t a = {xend - res, xend - 1, y, y}; al_push(pts, a); }
+	return init != pts->n;
+}
+/* Scanner.h:199-233 */
+static int scan_vertical(const scanner_t* sc, int kind, alist* pts, int x, int xmax, int ystart, int yend)
+{
+	if (xmax < 0) xmax = x;
+	const int xavg = (x + xmax) / 2;
+	if (ystart < 0) ystart = 0;
+	if (yend < 0 || yend > sc->h) yend = sc->h;
+	const int init = pts->n;
+	scan_state st;
+	ss_init(&st, kind);
+	for (int y = ystart; y < yend; ++y) {
+		const int res = ss_process(&st, test_pixel(sc, xavg, y));
+		if (res > 0) { anchor_t a = {xavg, xavg, y - res, y - 1}; al_push(pts, a); }
+	}
+	const int res = ss_process(&st, 0);
+	if (res > 0) { anchor_t a = {xavg, xavg, yend - res, yend - 1}; al_push(pts, a); }
+	return init != pts->n;
+}
+/* Scanner.h:235-275 */
+static int scan_diagonal(const scanner_t* sc, int kind, alist* pts, int xstart, int xend, int ystart, int yend)
+{
+	if (xend > sc->w) xend = sc->w;
+	if (yend > sc->h) yend = sc->h;
+	if (xstart < 0) { const int off = -xstart; xstart += off; ystart += off; }
+	if (ystart < 0) { const int off = -ystart; xstart += off; ystart += off; }
+	const int init = pts->n;
+	scan_state st;
+	ss_init(&st, kind);
+	int x = xstart, y = ystart;
+	for (; x < xend && y < yend; ++x, ++y) {
+		const int res = ss_process(&st, test_pixel(sc, x, y));
+		if (res > 0) { anchor_t a = {x - res, x - 1, y - res, y - 1}; al_push(pts, a); }
+	}
+	const int res = ss_process(&st, 0);
+	if (res > 0) { anchor_t a = {x - res, x - 1, y - res, y - 1}; al_push(pts, a); }
+	return init != pts->n;
+}
+
+/* t4_confirm_scan, Scanner.h:341-389: returns 1 and the (possibly grown) anchor in *hint */
+static int t4_confirm(const scanner_t* sc, int kind, anchor_t* hint, int merge_confirms)
+{
+	{
+		alist cf = {0, 0, 0};
+		const int xstart = hint->x - a_xrange(hint), xend = hint->xmax + a_xrange(hint), yavg = a_yavg(hint);
+		for (int dy = -1; dy <= 1; ++dy)
+			if (!scan_horizontal(sc, kind, &cf, yavg + dy, xstart, xend)) { free(cf.v); return 0; }
+		int confirm = 0;
+		for (int k = 0; k < cf.n; ++k)
+			if (a_mergeable(&cf.v[k], hint, sc->cutoff)) {
+				confirm = 1;
+				if (!merge_confirms) break;
+				a_merge(hint, &cf.v[k]);
+			}
+		free(cf.v);
+		if (!confirm) return 0;
+	}
+	{
+		alist cf = {0, 0, 0};
+		const int ystart = hint->y - a_yrange(hint), yend = hint->ymax + a_yrange(hint), xavg = a_xavg(hint);
+		for (int dx = -1; dx <= 1; ++dx)
+			if (!scan_vertical(sc, kind, &cf, xavg + dx, xavg + dx, ystart, yend)) { free(cf.v); return 0; }
+		int confirm = 0;
+		for (int k = 0; k < cf.n; ++k)
+			if (a_mergeable(&cf.v[k], hint, sc->cutoff)) {
+				confirm = 1;
+				if (!merge_confirms) break;
+				a_merge(hint, &cf.v[k]);
+			}
+		free(cf.v);
+		if (!confirm) return 0;
+	}
+	return 1;
+}
+
+/* on_t1_scan, Scanner.h:391-405: t2 column (:295-306) -> t3 diagonal (:308-339) -> t4 confirm */
+static void on_t1_scan(const scanner_t* sc, int kind, const anchor_t* found, alist* candidates, int merge_confirms)
+{
+	for (int k = 0; k < candidates->n; ++k)
+		if (a_mergeable(&candidates->v[k], found, sc->cutoff)) return;
+	alist col = {0, 0, 0};
+	scan_vertical(sc, kind, &col, found->x, found->xmax, found->y - 3 * a_xrange(found), found->ymax + 3 * a_xrange(found));
+	for (int k = 0; k < col.n; ++k) {
+		const anchor_t* p = &col.v[k];
+		alist dg = {0, 0, 0};
+		const int yr = a_yrange(p);
+		if (scan_diagonal(sc, kind, &dg, a_xavg(p) - 2 * yr, a_xavg(p) + 2 * yr, p->y - yr, p->ymax + yr)) {
+			int confirm = 0;
+			anchor_t merged = *p;
+			for (int q = 0; q < dg.n; ++q)
+				if (a_mergeable(&dg.v[q], p, sc->cutoff)) { confirm = 1; a_merge(&merged, &dg.v[q]); }
+			if (confirm && t4_confirm(sc, kind, &merged, merge_confirms)) al_push(candidates, merged);
+		}
+		free(dg.v);
+	}
+	free(col.v);
+}
+
+/* t1_scan_rows, Scanner.h:277-293 */
+static void t1_scan_rows(const scanner_t* sc, int kind, alist* candidates, int merge_confirms, int skip, int y, int yend, int xstart, int xend)
+{
+	if (skip <= 0) skip = sc->skip;
+	if (y < 0) y = skip;
+	if (yend < 0 || yend > sc->h) yend = sc->h;
+	alist pts = {0, 0, 0};
+	for (; y < yend; y += skip) scan_horizontal(sc, kind, &pts, y, xstart, xend);
+	for (int k = 0; k < pts.n; ++k) on_t1_scan(sc, kind, &pts.v[k], candidates, merge_confirms);
+	free(pts.v);
+}
+
+/* Scanner::scan for a w x h image of 0 / 255. anchors: up to 4 x {x, xmax, y, ymax} in the reference's order (top-left, top-right,
+ * bottom-left, bottom-right). Returns how many it found (Scanner.cpp:183-202). */
+int co_scan_anchors(const uint8_t* binary, int w, int h, int32_t* anchors16)
+{
+	scanner_t sc = {binary, w, h, (h < w ? h : w) / 60, w / 30};   /* Scanner.h:168-174: _skip, _mergeCutoff */
+	g_dbg_max_list = 0;
+	alist cand = {0, 0, 0};
+	t1_scan_rows(&sc, 114, &cand, 1, -1, -1, -1, -1, -1);            /* scan_primary, Scanner.cpp:171-181 */
+	/* filter_candidates, Scanner.cpp:79-103 (std::sort on <= 16 elements is an insertion sort: stable) */
+	unsigned cutoff = 0;
+	if (cand.n >= 3) {
+		for (int i = 1; i < cand.n; ++i) {
+			anchor_t key = cand.v[i];
+			int j = i - 1;
+			while (j >= 0 && a_size(&key) > a_size(&cand.v[j])) { cand.v[j + 1] = cand.v[j]; --j; }
+			cand.v[j + 1] = key;
+		}
+		unsigned long long cs = 0;
+		for (int i = 0; i < 3; ++i) cs += a_size(&cand.v[i]);
+		cutoff = (unsigned)cs;     /* `unsigned cutoff` accumulates the unsigned long long sizes */
+		cutoff /= 8;
+		int i = 0;
+		for (; i < cand.n; ++i) if (a_size(&cand.v[i]) < cutoff) break;
+		if (i > 3) i = 3;
+		if (i < cand.n) cand.n = i;
+	}
+	/* sort_top_to_bottom, Scanner.cpp:105-139 */
+	if (cand.n >= 3) {
+		int cx[3], cy[3];
+		for (int i = 0; i < 3; ++i) { cx[i] = a_xavg(&cand.v[i]); cy[i] = a_yavg(&cand.v[i]); }
+		const int ex[3] = {cx[1] - cx[2], cx[2] - cx[0], cx[0] - cx[1]}, ey[3] = {cy[1] - cy[2], cy[2] - cy[0], cy[0] - cy[1]};
+		int tl = 0, maxd = 0;
+		for (int i = 0; i < 3; ++i) { const int d = ex[i] * ex[i] + ey[i] * ey[i]; if (d > maxd) { tl = i; maxd = d; } }
+		const int dep = tl - 1 < 0 ? 2 : tl - 1, inc = tl + 1 >= 3 ? 0 : tl + 1;
+		const int ix = -ey[inc], iy = ex[inc];
+		const int ox = ex[dep] - ix, oy = ey[dep] - iy;
+		int tr, bl;
+		if (ox * ox + oy * oy < ex[dep] * ex[dep] + ey[dep] * ey[dep]) { tr = inc; bl = dep; }
+		else { tr = dep; bl = inc; }
+		anchor_t a0 = cand.v[tl], a1 = cand.v[tr], a2 = cand.v[bl];
+		cand.v[0] = a0; cand.v[1] = a1; cand.v[2] = a2;
+		cand.n = 3;
+	}
+	/* add_bottom_right_corner, Scanner.cpp:141-181 */
+	if (cand.n == 3 && cutoff != 0) {
+		const anchor_t* a = cand.v;
+		const int mr0 = a_max_range(&a[0]), mr1 = a_max_range(&a[1]), mr2 = a_max_range(&a[2]);
+		const double top_scalar = mr2 / (double)(mr1 > mr0 ? mr1 : mr0);
+		const int tex = (int)((a_xavg(&a[1]) - a_xavg(&a[0])) * top_scalar), tey = (int)((a_yavg(&a[1]) - a_yavg(&a[0])) * top_scalar);
+		const int g1x = a_xavg(&a[2]) + tex, g1y = a_yavg(&a[2]) + tey;
+		const double left_scalar = mr1 / (double)(mr2 > mr0 ? mr2 : mr0);
+		const int lex = (int)((a_xavg(&a[2]) - a_xavg(&a[0])) * left_scalar), ley = (int)((a_yavg(&a[2]) - a_yavg(&a[0])) * left_scalar);
+		const int g2x = a_xavg(&a[1]) + lex, g2y = a_yavg(&a[1]) + ley;
+		const int ccx = (g1x + g2x) / 2, ccy = (g1y + g2y) / 2;
+		int mrmax = mr0 > mr1 ? mr0 : mr1;
+		if (mr2 > mrmax) mrmax = mr2;
+		const int range = (int)((float)mrmax * 2.0f);
+		alist c2 = {0, 0, 0};
+		t1_scan_rows(&sc, 122, &c2, 0, sc.skip / 2, ccy - range, ccy + range, ccx - range, ccx + range);
+		for (int k = 0; k < c2.n; ++k)
+			if (a_size(&c2.v[k]) > cutoff) { al_push(&cand, c2.v[k]); break; }
+		free(c2.v);
+	}
+	const int n = cand.n < 4 ? cand.n : 4;
+	for (int i = 0; i < n; ++i) { anchors16[4 * i] = cand.v[i].x; anchors16[4 * i + 1] = cand.v[i].xmax; anchors16[4 * i + 2] = cand.v[i].y; anchors16[4 * i + 3] = cand.v[i].ymax; }
+	const int total = cand.n;
+	free(cand.v);
+	return total;
+}
+
+/* Extractor::extract (Extractor.h:29-45): 0 FAILURE, 1 SUCCESS, 2 NEEDS_SHARPEN; corners8 = Corners::all() (Corners.h:45-53), out = the
+ * deskewed 1024x1024 RGB8 frame. */
+int co_extract(const uint8_t* rgb, int w, int h, uint8_t* out1024, float* corners8)
+{
+	uint8_t* bin = (uint8_t*)malloc((size_t)w * h);
+	if (co_scan_preprocess(rgb, w, h, bin) < 0) { free(bin); return 0; }
+	int32_t an[16];
+	const int found = co_scan_anchors(bin, w, h, an);
+	free(bin);
+	if (found < 4) return 0;
+	int cx[4], cy[4];
+	for (int i = 0; i < 4; ++i) { cx[i] = (an[4 * i] + an[4 * i + 1]) / 2; cy[i] = (an[4 * i + 2] + an[4 * i + 3]) / 2; }
+	float c8[8];
+	for (int i = 0; i < 4; ++i) { c8[2 * i] = (float)cx[i]; c8[2 * i + 1] = (float)cy[i]; }
+	if (corners8) memcpy(corners8, c8, sizeof c8);
+	co_deskew(rgb, w, h, c8, out1024);
+	/* Corners::is_granular_scale({1024, 1024}), Corners.h:55-73: every edge longer than the output in x or in y, else we are upscaling */
+	const int e[4][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}};   /* tl-tr, tr-br, br-bl, bl-tl */
+	int granular = 1;
+	for (int k = 0; k < 4; ++k) {
+		const int a = e[k][0], b = e[k][1];
+		if (!(abs(cx[a] - cx[b]) > CO_IMG || abs(cy[a] - cy[b]) > CO_IMG)) granular = 0;
+	}
+	return granular ? 1 : 2;
+}

@@ -371,6 +371,19 @@ int ref_scan_corners(const uint8_t* rgb, unsigned w, unsigned h, float* corners8
 	return 4;
 }
 
+// Scanner(img).scan() raw: up to 4 anchors as {x, xmax, y, ymax}; returns how many scan() produced
+int ref_scan_anchors(const uint8_t* rgb, unsigned w, unsigned h, int32_t* out16)
+{
+	cv::Mat img((int)h, (int)w, CV_8UC3, (void*)rgb);
+	Scanner scanner(img);
+	std::vector<Anchor> points = scanner.scan();
+	for (size_t i = 0; i < points.size() && i < 4; ++i)
+	{
+		out16[4 * i] = points[i].x(); out16[4 * i + 1] = points[i].xmax(); out16[4 * i + 2] = points[i].y(); out16[4 * i + 3] = points[i].ymax();
+	}
+	return (int)points.size();
+}
+
 // Deskewer(0, image_size, anchor_size).deskew(img, corners) (Deskewer.h:26-40) for explicit corners: out = 1024*1024*3
 int ref_deskew(const uint8_t* rgb, unsigned w, unsigned h, const float* corners8, uint8_t* out)
 {

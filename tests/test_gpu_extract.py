@@ -128,3 +128,52 @@ def test_other_capture_sizes_match_oracle(hip_decoder, synth, oracle, size, quad
     desk = hip_decoder.deskew_batch(cam[None], far[None])
     oracle.co_deskew(P(cam), w, h, far.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), P(wantd))
     assert (desk[0] == wantd).all()
+
+
+def test_extract_batch_matches_oracle_on_captures_that_work_and_that_fail(hip_decoder, synth, oracle):
+    """Extractor::extract entirely on the device (anchor search included): status, corners and deskewed frames == the oracle's co_extract
+    (itself pinned to the reference's Scanner / Extractor in tests/test_oracle_vs_ref.py), per capture size"""
+    from tests.test_oracle_vs_ref import scan_cases
+    cams = scan_cases(synth)
+    by_size = {}
+    for k, cam in enumerate(cams):
+        by_size.setdefault(cam.shape, []).append(k)
+    ok = 0
+    for shape, idx in by_size.items():
+        batch = np.ascontiguousarray(np.stack([cams[k] for k in idx]))
+        status, corners, frames = hip_decoder.extract_batch(batch)
+        H, W = shape[:2]
+        for j, k in enumerate(idx):
+            want = np.zeros((1024, 1024, 3), np.uint8)
+            c8 = (ctypes.c_float * 8)()
+            rc = oracle.co_extract(P(cams[k]), W, H, P(want), c8)
+            assert status[j] == rc, f"capture {k} {shape}: status {status[j]} vs {rc}"
+            if rc:
+                assert list(corners[j]) == list(c8), k
+                assert (frames[j] == want).all(), f"capture {k}: {(frames[j] != want).sum()} bytes differ"
+                ok += 1
+            else:
+                assert not frames[j].any()
+    assert ok >= 4
+
+
+def test_scan_extract_decode_chain_equals_the_reference_chain(hip_decoder, synth, ref):
+    """cimbard_scan_extract_decode / cimbar.cpp's loop for a batch of captures, nothing leaving the device in between: the chunks are the
+    reference's (Extractor::extract -> Decoder::decode_fountain with the sharpen verdict), a failed extraction delivers nothing"""
+    payload, cams = captures(synth)
+    n, h, w = cams.shape[:3]
+    blank = np.zeros_like(cams[0])
+    batch = np.ascontiguousarray(np.concatenate([cams, blank[None]], 0))       # the last capture has no anchors at all
+    hip_decoder.reset_ccm()
+    total, chunks, masks, status = hip_decoder.scan_extract_decode_batch(batch, preprocess=-1)
+    assert status[n] == 0 and masks[n] == 0 and not chunks[n].any()
+    ref.ref_reset_ccm()
+    want_total = 0
+    for k in range(n):
+        ext = np.zeros((1024, 1024, 3), np.uint8)
+        rc = ref.ref_extract(P(cams[k]), w, h, P(ext))
+        assert status[k] == rc
+        r, wchunks, wmask = pyref.ref_decode(ext, rc == 2, 2, 0)
+        assert masks[k] == wmask and (chunks[k] == wchunks).all(), k
+        want_total += r
+    assert total == want_total

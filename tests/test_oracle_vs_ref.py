@@ -206,3 +206,53 @@ def test_extractor_stage_other_capture_sizes(ref, oracle, synth, size, quad):
     ref.ref_deskew(P(cam), w, h, corners, P(o1))
     oracle.co_deskew(P(cam), w, h, corners, P(o2))
     assert (o1 == o2).all()
+
+
+def scan_cases(synth, count=14, seed=5):
+    """synthetic captures of several sizes / orientations, some too small or partly out of view (the search then fails -- identically)"""
+    payload, clean = F.clean_frames(synth, 4, seed=9)
+    g = np.random.default_rng(seed)
+    out = []
+    for it in range(count):
+        W, H = [(1920, 1080), (1280, 720), (1080, 1920), (2560, 1440)][it % 4]
+        s = min(W, H)
+        cx, cy = W / 2 + g.integers(-W // 10, W // 10), H / 2 + g.integers(-H // 12, H // 12)
+        half = s * (0.34 + 0.15 * g.random())
+
+        def j():
+            return int(g.integers(-s // 25, s // 25))
+        quad = ((int(cx - half) + j(), int(cy - half) + j()), (int(cx + half) + j(), int(cy - half) + j()),
+                (int(cx - half) + j(), int(cy + half) + j()), (int(cx + half) + j(), int(cy + half) + j()))
+        if it % 7 == 3:
+            quad = tuple((x + W // 3, y) for x, y in quad)
+        cam = np.ascontiguousarray(F.camera_frame(clean[it % 4], width=W, height=H, quad=quad, background=int(g.integers(0, 256)),
+                                                  blur=float(g.choice([0, 0, 0.6, 1.2]))))
+        if it % 5 == 4:
+            cam = F.add_noise(cam, 25, it)
+        out.append(cam)
+    return out
+
+
+def test_anchor_scan_and_extract_restatement_match_the_reference(ref, oracle, synth):
+    """SURVEY 8(f) rank 2, the anchor search: oracle co_scan_anchors / co_extract == the reference's Scanner::scan / Extractor::extract
+    (anchor rectangles, how many were found, the return code, the deskewed frame) on captures that succeed AND on ones that fail"""
+    found4 = 0
+    for it, cam in enumerate(scan_cases(synth)):
+        H, W = cam.shape[:2]
+        a, b = np.zeros(16, np.int32), np.zeros(16, np.int32)
+        na = ref.ref_scan_anchors(P(cam), W, H, P(a))
+        binimg = np.zeros((H, W), np.uint8)
+        oracle.co_scan_preprocess(P(cam), W, H, P(binimg))
+        nb = oracle.co_scan_anchors(P(binimg), W, H, P(b))
+        assert na == nb, it
+        k = 4 * min(na, 4)
+        assert (a[:k] == b[:k]).all(), it
+        o1, o2 = np.zeros((1024, 1024, 3), np.uint8), np.zeros((1024, 1024, 3), np.uint8)
+        c8 = (ctypes.c_float * 8)()
+        r1 = ref.ref_extract(P(cam), W, H, P(o1))
+        r2 = oracle.co_extract(P(cam), W, H, P(o2), c8)
+        assert r1 == r2, it
+        if r1:
+            assert (o1 == o2).all(), it
+            found4 += 1
+    assert found4 >= 4
