@@ -9,8 +9,11 @@
 //                                                                escrow_buffer_writer, null_stream -- used UNCHANGED
 //     class CimbReader         src/lib/cimb_translator/          cimbar_amd::CimbReader        (read / read_color / done / num_reads over the
 //                              CimbReader.h:13-41                                               GPU's per-cell results, linear cell order)
+//     class CimbDecoder        cimb_translator/CimbDecoder.h     cimbar_amd::CimbDecoder       (what CimbReader's constructor takes; owns nothing, names the context)
 //     class Deskewer           src/lib/extractor/Deskewer.h:12-40 cimbar_amd::Deskewer          (deskew(img, corners) -> 1024x1024 frame; plus
 //     Scanner::preprocess_image src/lib/extractor/Scanner.h:148-165                              scan_preprocess(img) -> the binary image Scanner scans)
+//     class Extractor          src/lib/extractor/Extractor.h:11-45 cimbar_amd::Extractor        (extract(img, out) -> FAILURE / SUCCESS / NEEDS_SHARPEN, the
+//                                                                                               anchor search included, on the device)
 //
 // Header-only; link against libcimbar_hip.so. No exceptions, no OpenCV requirement: MAT is anything shaped like cv::Mat
 // (`data`, `cols`, `rows`, `step`), e.g. cv::Mat, cv::UMat::getMat(), or cimbar_amd::image_view below.
@@ -147,9 +150,36 @@ protected:
 // construction; read() then walks the cells in linear index order (the reference walks them in flood order, but its caller
 // Decoder::do_decode places every result by pos.i, Decoder.h:84-97, so the order is not observable there) and returns the
 // 4 symbol bits plus the drifted position the colour pass used; read_color() returns the 2 colour bits of that cell.
+// CimbDecoder as CimbReader's constructor wants it (cimb_translator/CimbDecoder.h: CimbDecoder(symbol_bits, color_bits, dark, ahashThreshold)):
+// the tile hashes and the colour-correction state live in the device context, so this only names one. Mode B only: 4 symbol bits, 2 colour bits.
+class CimbDecoder
+{
+public:
+	explicit CimbDecoder(Decoder& decoder, unsigned symbol_bits = 4, unsigned color_bits = 2, bool dark = true, unsigned char ahash_threshold = 0xFF)
+	    : _dec(decoder), _ok(symbol_bits == 4 && color_bits == 2 && dark)
+	{
+		(void)ahash_threshold;
+	}
+	bool good() const { return _ok && _dec.good(); }
+	Decoder& decoder() { return _dec; }
+
+protected:
+	Decoder& _dec;
+	bool _ok;
+};
+
 class CimbReader
 {
 public:
+	// CimbReader(const cv::Mat& img, CimbDecoder& decoder, unsigned color_mode, bool needs_sharpen = false, int color_correction = 2)
+	// (cimb_translator/CimbReader.h:16-17). color_mode: only the reference's default for mode B (1) exists here.
+	template <typename MAT>
+	CimbReader(const MAT& img, CimbDecoder& decoder, unsigned color_mode, bool needs_sharpen = false, int color_correction = 2)
+	    : CimbReader(img, decoder.decoder(), needs_sharpen, color_correction)
+	{
+		if (!decoder.good() || color_mode != 1) _good = false;
+	}
+
 	template <typename MAT>
 	CimbReader(const MAT& img, Decoder& decoder, bool needs_sharpen = false, int color_correction = 2)
 	{
@@ -211,6 +241,8 @@ struct image
 	image(const image& o) : pixels(o.pixels), data(nullptr), cols(o.cols), rows(o.rows), step(o.step), channels(o.channels) { data = pixels.data(); }
 	image& operator=(const image& o) { pixels = o.pixels; data = pixels.data(); cols = o.cols; rows = o.rows; step = o.step; channels = o.channels; return *this; }
 	bool empty() const { return pixels.empty(); }
+	int type() const { return channels; }
+	void create(int r, int c, int type_channels) { *this = image(c, r, type_channels); }
 };
 
 // Deskewer (Deskewer.h:12-40) and the image preparation of Scanner (Scanner.h:148-165) over the context of a cimbar_amd::Decoder.
@@ -255,6 +287,9 @@ public:
 		return out;
 	}
 
+	template <typename MAT>
+	static const unsigned char* dense(const MAT& img, std::vector<unsigned char>& packed) { return dense_rgb(img, packed); }
+
 protected:
 	template <typename MAT>
 	static const unsigned char* dense_rgb(const MAT& img, std::vector<unsigned char>& packed)
@@ -269,6 +304,45 @@ protected:
 	}
 
 	Decoder& _dec;
+};
+
+// Extractor (extractor/Extractor.h:11-45): Scanner + Corners + Deskewer, all on the device. MAT is anything with data / cols / rows / step
+// that can be re-shaped with create(rows, cols, type) and reports type() -- cv::Mat as is, or cimbar_amd::image.
+class Extractor
+{
+public:
+	static constexpr int FAILURE = 0;
+	static constexpr int SUCCESS = 1;
+	static constexpr int NEEDS_SHARPEN = 2;
+
+	// Extractor(padding, image_size, anchor_size): only the defaults the reference's callers use (0, Config's 1024x1024, Config's 30)
+	explicit Extractor(Decoder& decoder) : _dec(decoder) {}
+
+	template <typename MAT>
+	int extract(const MAT& img, MAT& out)
+	{
+		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return FAILURE;
+		std::vector<unsigned char> packed;
+		const unsigned char* src = Deskewer::dense(img, packed);
+		std::vector<unsigned char> frame((size_t)CIMBAR_HIP_FRAME_DIM * CIMBAR_HIP_FRAME_DIM * 3);
+		int status = 0;
+		if (cimbar_hip_extract_batch(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, frame.data(), &status, _corners,
+		                             CIMBAR_HIP_MEM_HOST, nullptr) != 0)
+			return FAILURE;
+		if (status <= 0) return FAILURE;
+		out.create(CIMBAR_HIP_FRAME_DIM, CIMBAR_HIP_FRAME_DIM, img.type());
+		for (int y = 0; y < CIMBAR_HIP_FRAME_DIM; ++y)
+			for (size_t k = 0; k < (size_t)CIMBAR_HIP_FRAME_DIM * 3; ++k)
+				out.data[(size_t)y * out.step + k] = frame[(size_t)y * CIMBAR_HIP_FRAME_DIM * 3 + k];
+		return status;
+	}
+
+	// Corners::all() of the last extract: top-left, top-right, bottom-left, bottom-right (x, y)
+	const float* corners() const { return _corners; }
+
+protected:
+	Decoder& _dec;
+	float _corners[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 }  // namespace cimbar_amd

@@ -29,3 +29,24 @@ def test_cpp_decoder_adapter(tmp_path, synth, hip_decoder):
     res = subprocess.run([str(exe), str(tmp_path / "frames.bin"), str(tmp_path / "payload.bin"), str(tmp_path / "cells.bin"), str(n)],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.startswith("OK"), res.stdout + res.stderr
+
+
+def test_dropin_against_the_reference_headers(tmp_path, synth, ref):
+    """tests/cpp/test_dropin.cpp, compiled in the build container against the reference's own headers (cv::Mat via the shim,
+    fountain_decoder_sink, concurrent_fountain_decoder_sink + wirehair): a wirehair stream of a file, rendered by the reference encoder, goes
+    through cimbar_amd::Decoder::decode_fountain into the reference's sinks and the file comes back; captures go through cimbar_amd::Extractor"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_dropin not built (needs /root/reference at build time: make -C oracle dropin)")
+    from oracle.pyref import P
+    size, n = 60000, 14            # 97 wirehair blocks -> complete within 9 frames
+    data = np.random.default_rng(77).integers(0, 256, size, dtype=np.uint8)
+    frames = np.zeros((n, 1024, 1024, 3), np.uint8)
+    assert ref.ref_encode_fountain(P(data), size, 9, 0, n, P(frames)) == n
+    frames.tofile(tmp_path / "frames.bin")
+    data.tofile(tmp_path / "file.bin")
+    cams = np.ascontiguousarray(np.stack([F.camera_frame(frames[k], quad=((500, 40), (1480, 70), (470, 1030), (1500, 1000)), background=10) for k in range(2)]))
+    cams.tofile(tmp_path / "caps.bin")
+    res = subprocess.run([exe, str(tmp_path / "frames.bin"), str(n), str(tmp_path / "file.bin"), str(tmp_path / "caps.bin"), "1920", "1080", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
