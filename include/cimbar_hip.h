@@ -160,6 +160,24 @@ int64_t cimbar_hip_scan_extract_decode_batch(cimbar_hip_ctx* ctx, const uint8_t*
                                              int preprocess, int color_correction, uint8_t* chunks, uint32_t* masks, int* status, int out_mem,
                                              void* hip_stream);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------------------------------------------------
+ * Frames are independent, so each GPU decodes its own slab with its own context; afterwards every rank's n x (7500 chunk bytes + 1 mask
+ * word) are gathered on `root` in rank order (== frame order for contiguous slabs), where the host feeds the single fountain_decoder_sink
+ * -- the shape of the reference's worker pool -> one sink (web/recv-worker.js:47-64, web/recv.js:36). The gather is ncclGather over RCCL /
+ * xGMI (/opt/rocm/include/rccl/rccl.h:745); RCCL is loaded on first use, the library does not link against it.
+ *   comm_init_all   : one process driving ndev GPUs (one context + one comm per device; call gather_chunks from one thread per device or
+ *                     inside the caller's own group). devices NULL = 0..ndev-1. Fills out[0..ndev).
+ *   comm_unique_id / comm_init_rank : one process per GPU; rank 0 makes the 128-byte id and hands it to the others by its own means.
+ *   gather_chunks   : chunks / masks: this rank's n frames (device memory); all_chunks / all_masks: nranks * n frames on root (device
+ *                     memory, may be NULL elsewhere). Enqueued on hip_stream; returns 0. */
+typedef struct cimbar_hip_comm cimbar_hip_comm;
+int cimbar_hip_comm_init_all(int ndev, const int* devices, cimbar_hip_comm** out);
+int cimbar_hip_comm_unique_id(uint8_t id128[128]);
+int cimbar_hip_comm_init_rank(const uint8_t id128[128], int nranks, int rank, int device, cimbar_hip_comm** out);
+void cimbar_hip_comm_destroy(cimbar_hip_comm* comm);
+int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int root, const uint8_t* chunks, const uint32_t* masks, int n,
+                             uint8_t* all_chunks, uint32_t* all_masks, void* hip_stream);
+
 /* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
 enum {
 	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */

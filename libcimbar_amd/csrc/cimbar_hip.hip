@@ -89,3 +89,4 @@ struct Tables {
 }  // namespace
 
 #include "host.hip.inc"
+#include "comm.hip.inc"

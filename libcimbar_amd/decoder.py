@@ -26,7 +26,8 @@ EXPORTS = (
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
-    "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch",
+    "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
+    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks",
 )
 
 
@@ -78,6 +79,16 @@ def load_library(path=None):
     lib.cimbar_hip_extract_batch.restype = i32
     lib.cimbar_hip_scan_extract_decode_batch.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     lib.cimbar_hip_scan_extract_decode_batch.restype = i64
+    lib.cimbar_hip_comm_init_all.argtypes = [i32, vp, ctypes.POINTER(vp)]
+    lib.cimbar_hip_comm_init_all.restype = i32
+    lib.cimbar_hip_comm_unique_id.argtypes = [vp]
+    lib.cimbar_hip_comm_unique_id.restype = i32
+    lib.cimbar_hip_comm_init_rank.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+    lib.cimbar_hip_comm_init_rank.restype = i32
+    lib.cimbar_hip_comm_destroy.argtypes = [vp]
+    lib.cimbar_hip_comm_destroy.restype = None
+    lib.cimbar_hip_gather_chunks.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.cimbar_hip_gather_chunks.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -102,6 +113,19 @@ def tile_hashes():
     out = np.zeros(16, dtype=np.uint64)
     load_library().cimbar_hip_tile_hashes(out.ctypes.data)
     return out
+
+
+def comm_unique_id():
+    """128 bytes naming a new RCCL communicator (rank 0 makes it, every rank passes it to HipDecoder.comm_init_rank)"""
+    buf = (ctypes.c_uint8 * 128)()
+    rc = load_library().cimbar_hip_comm_unique_id(buf)
+    if rc != 0:
+        raise CimbarHipError(f"cimbar_hip_comm_unique_id failed: {rc} (RCCL not available?)")
+    return bytes(buf)
+
+
+def comm_destroy(comm):
+    load_library().cimbar_hip_comm_destroy(comm)
 
 
 _ERR = {-1: "EINVAL", -2: "EDIM", -3: "ENODEVICE", -4: "EHIP", -5: "ENOMEM"}
@@ -307,6 +331,20 @@ class HipDecoder:
         self._check(self._lib.cimbar_hip_encode_batch(self._ctx, ctypes.c_void_p(payload_ptr), int(n), MEM_DEVICE, ctypes.c_void_p(rgb_ptr),
                                                       MEM_DEVICE, ctypes.c_void_p(stream) if stream else None),
                     "cimbar_hip_encode_batch(device)")
+
+    # ------------------------------------------------------------------ multi-GPU exchange through the library's own RCCL binding
+    def comm_init_rank(self, uid, nranks, rank):
+        """join the communicator named by the 128-byte `uid` (bytes from comm_unique_id() on rank 0); returns an opaque handle"""
+        comm = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        self._check(self._lib.cimbar_hip_comm_init_rank(buf, int(nranks), int(rank), int(self.device), ctypes.byref(comm)), "cimbar_hip_comm_init_rank")
+        return comm
+
+    def gather_chunks(self, comm, root, chunks_ptr, masks_ptr, n, all_chunks_ptr, all_masks_ptr, stream=None):
+        self._check(self._lib.cimbar_hip_gather_chunks(self._ctx, comm, int(root), ctypes.c_void_p(chunks_ptr), ctypes.c_void_p(masks_ptr), int(n),
+                                                       ctypes.c_void_p(all_chunks_ptr) if all_chunks_ptr else None,
+                                                       ctypes.c_void_p(all_masks_ptr) if all_masks_ptr else None,
+                                                       ctypes.c_void_p(stream) if stream else None), "cimbar_hip_gather_chunks")
 
     # ------------------------------------------------------------------ state / taps / timing
     def reset_ccm(self):

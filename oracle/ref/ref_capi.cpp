@@ -343,6 +343,27 @@ int ref_interleave_reverse(unsigned size, unsigned blocks, unsigned partitions, 
 // fountain_decoder_sink (fountain_decoder_sink.h:53-214) -- the rank-0 wirehair sink of BASELINE config 4
 int ref_sink_reset(unsigned chunk_size) { g_sink = std::make_shared<fountain_decoder_sink>(chunk_size); return 0; }
 int64_t ref_sink_decode_frame(const uint8_t* buf, unsigned size) { return g_sink ? g_sink->decode_frame((const char*)buf, size) : -100; }
+// n frames' worth of chunk slots fed in frame order then chunk order (what multigpu.feed_sink does call by call); a finished stream is
+// recovered into `out` at once (which also marks it done, so later chunks of it are ignored: fountain_decoder_sink.h:77-96,146-148).
+// Returns the number of chunks handed to the sink; *completed_id = the file id once complete (else 0).
+int64_t ref_sink_feed_batch(const uint8_t* chunks, const uint32_t* masks, unsigned n, unsigned chunks_per_frame, unsigned chunk_size, uint8_t* out,
+                            unsigned out_size, uint32_t* completed_id)
+{
+	if (!g_sink) return -100;
+	int64_t fed = 0;
+	for (unsigned f = 0; f < n; ++f)
+		for (unsigned j = 0; j < chunks_per_frame; ++j)
+		{
+			if (!(masks[f] & (1u << j))) continue;
+			++fed;
+			int64_t r = g_sink->decode_frame((const char*)chunks + ((size_t)f * chunks_per_frame + j) * chunk_size, chunk_size);
+			if (r > 0)
+			{
+				if (out && g_sink->recover((uint32_t)r, out, out_size) && completed_id) *completed_id = (uint32_t)r;
+			}
+		}
+	return fed;
+}
 int ref_sink_is_done(uint32_t id) { return g_sink && g_sink->is_done(id) ? 1 : 0; }
 int ref_sink_recover(uint32_t id, uint8_t* out, unsigned size) { return g_sink && g_sink->recover(id, out, size) ? 1 : 0; }
 

@@ -53,3 +53,33 @@ def test_fountain_stream_through_sharded_decode_and_single_sink(hip_decoder, ref
     assert len(done) == 1, res[:10]
     assert hashlib.sha256(out.tobytes()).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()
     assert sum(1 for r in res if r == -1) > 0          # chunks after completion are ignored (fountain_decoder_sink.h:146-148)
+
+
+def test_library_gather_with_one_rank(hip_decoder):
+    """cimbar_hip_gather_chunks (ncclGather over RCCL, bound by the library itself) with a one-rank communicator: the gathered buffers are
+    the rank's own chunks and masks -- the N = 1 case of the exchange a C++ host runs per batch (the N > 1 path needs an N-GPU node)"""
+    from libcimbar_amd import decoder as D
+    dev = torch.device("cuda", 0)
+    n = 5
+    g = torch.Generator(device="cpu").manual_seed(3)
+    chunks = torch.randint(0, 256, (n, modeb.FRAME_BYTES), dtype=torch.uint8, generator=g).to(dev)
+    masks = torch.tensor([0xFFF, 0x8e0, 0, 0x3cf, 1], dtype=torch.int32, device=dev)
+    all_c = torch.zeros_like(chunks)
+    all_m = torch.zeros_like(masks)
+    uid = D.comm_unique_id()
+    comm = hip_decoder.comm_init_rank(uid, 1, 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    hip_decoder.gather_chunks(comm, 0, chunks.data_ptr(), masks.data_ptr(), n, all_c.data_ptr(), all_m.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool((all_c == chunks).all()) and bool((all_m == masks).all())
+    D.comm_destroy(comm)
+
+
+def test_bench_config4_small(hip_decoder, ref):
+    """bench.py --config 4 at a reduced size on one GPU: slabs through the pipelined entry point, sink fed, file recovered"""
+    import argparse
+    from libcimbar_amd import config4
+    dev = torch.device("cuda", 0)
+    line = config4.bench(hip_decoder, dev, 0, 1, argparse.Namespace(frames=32, steps=1, warmup=1))
+    assert line["chunks_match_encoded_stream"] and line["sink"]["file_recovered_sha256_match"] is True
+    assert line["scaling"] == "strong" and line["config"]["frames_total"] == 256
