@@ -57,6 +57,9 @@ int cimbar_hip_bufsize(void);
  * (CimbDecoder.cpp:58-66,87-99: getTile -> average_hash). Host-only arithmetic (works without a device); returns 16. */
 int cimbar_hip_tile_hashes(uint64_t out16[16]);
 
+/* the HIP device ordinal the context lives on */
+int cimbar_hip_device(const cimbar_hip_ctx* ctx);
+
 /* human-readable text of the last failure on this context (never NULL) */
 const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
 

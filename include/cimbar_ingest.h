@@ -1,0 +1,59 @@
+/* cimbar_ingest.h -- host-side ingest for the MI355X cimbar decode path: what stands between image FILES and the
+ * device-resident frames include/cimbar_hip.h wants. It replaces, for that step only, the front of ./cimbar's decode loop
+ *     cv::imread(path) + cv::cvtColor(BGR2RGB)        /root/reference/src/exe/cimbar/cimbar.cpp:132-133 (loop :124-162)
+ * with a pool of PNG-decoding host threads feeding a ring of pinned batches, whose host->device copies run on a copy stream and overlap
+ * the decode of the batch before (cimbar_hip_decode_batch_pipelined). Plain C ABI, C++ inside (libcimbar_ingest.so links zlib, pthreads
+ * and libcimbar_hip.so). PNG only (8/16-bit gray, RGB, RGBA, palette; non-interlaced) -- what the reference's encoder writes. */
+#ifndef CIMBAR_INGEST_H
+#define CIMBAR_INGEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cimbar_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	CIMBAR_INGEST_EFORMAT = -20,   /* not a PNG this decoder handles (interlaced, unknown colour type, corrupt stream) */
+	CIMBAR_INGEST_EIO = -21,       /* a file could not be read */
+	CIMBAR_INGEST_ESIZE = -22      /* an image is not 1024x1024 (frames must be deskewed already: the --no-deskew path, cimbar.cpp:136) */
+};
+
+/* One PNG in memory -> tightly packed RGB8 (what cv::imread + BGR2RGB hands the decoder: alpha dropped, gray replicated).
+ * rgb may be NULL to query the size: *width / *height are always set. Returns 0 or a negative code. */
+int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height);
+
+typedef struct cimbar_ingest cimbar_ingest;
+
+/* called once per batch, in frame order, from the thread that called cimbar_ingest_run_*: chunks = n * 7500 bytes, masks = n words (host
+ * memory, valid during the call); first_frame = index of the batch's first frame in the input list. Return non-zero to stop early
+ * (e.g. the fountain sink is complete). */
+typedef int (*cimbar_ingest_sink_fn)(void* user, const uint8_t* chunks, const uint32_t* masks, int first_frame, int n);
+
+/* threads: PNG decode threads (<= 0: one per hardware thread, at most 64); batch_frames: frames per device batch (<= 0: 64);
+ * ring: batches in flight between the host pool and the device (2..4, <= 0: 3) */
+int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out);
+void cimbar_ingest_destroy(cimbar_ingest* ing);
+const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
+
+/* ./cimbar --no-deskew img1.png img2.png ... (cimbar.cpp:124-162, fountain mode): every file is a deskewed 1024x1024 frame. Files that
+ * cannot be read or are not 1024x1024 PNGs are skipped like the reference skips frames it cannot decode (their slots deliver nothing).
+ * Returns the total good bytes (sum of what Decoder::decode_fountain would have returned per frame) or a negative code. */
+int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, int nfiles, int should_preprocess, int color_correction,
+                                cimbar_ingest_sink_fn sink, void* user);
+
+/* The same pipeline for frames that are already raw RGB8 in (pageable or pinned) host memory: staging into the pinned ring, H2D on the
+ * copy stream, decode and D2H all overlapped. */
+int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, int should_preprocess, int color_correction,
+                              cimbar_ingest_sink_fn sink, void* user);
+
+/* seconds spent in the last run: [0] wall, [1] PNG decode / staging (summed over threads), [2] waiting for the device */
+int cimbar_ingest_timings(const cimbar_ingest* ing, double out3[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIMBAR_INGEST_H */

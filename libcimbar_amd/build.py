@@ -49,6 +49,27 @@ def build_hip(force=False, verbose=False, out=OUT, defines=()):
     return out
 
 
+INGEST_SRC = os.path.join(HERE, "csrc", "ingest.cpp")
+INGEST_OUT = os.path.join(HERE, "libcimbar_ingest.so")
+INGEST_HEADER = os.path.join(os.path.dirname(HERE), "include", "cimbar_ingest.h")
+
+
+def build_ingest(force=False, verbose=False):
+    """libcimbar_ingest.so: the host-side PNG pool + pinned ring in front of the device path (plain C++, g++; HIP runtime API only)."""
+    deps = [INGEST_SRC, INGEST_HEADER, HEADER]
+    if not force and os.path.exists(INGEST_OUT) and os.path.getmtime(INGEST_OUT) >= max(os.path.getmtime(p) for p in deps) \
+            and os.path.getmtime(INGEST_OUT) >= os.path.getmtime(OUT):
+        return INGEST_OUT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", "-o", INGEST_OUT + ".tmp",
+           INGEST_SRC, f"-L{HERE}", "-lcimbar_hip", f"-L{rocm}/lib", "-lamdhip64", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{rocm}/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(INGEST_OUT + ".tmp", INGEST_OUT)
+    return INGEST_OUT
+
+
 def build_spilltest(force=False, verbose=False):
     """The test-only variant whose flood heap keeps 1024 slots in LDS (everything deeper goes through the spill path)."""
     return build_hip(force, verbose, OUT_SPILLTEST, ("CIMBAR_HEAP_LDS=1024",))
@@ -57,3 +78,4 @@ def build_spilltest(force=False, verbose=False):
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
     print(build_spilltest(force="--force" in sys.argv, verbose=True))
+    print(build_ingest(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,383 @@
+// ingest.cpp -> libcimbar_ingest.so: the host side in front of the device decode path (include/cimbar_ingest.h).
+//
+//   files / host frames --[pool of host threads: read + PNG decode (zlib inflate + un-filter) | staging copy]--> pinned batch (ring of R)
+//        --[copy stream: hipMemcpyAsync H2D]--> device batch --[context streams: cimbar_hip_decode_batch_pipelined]--> chunks, masks
+//        --[output stream: D2H into pinned memory]--> sink callback, in frame order
+//
+// The batch being filled, the batch being copied and the batches being decoded are different ring slots, so PNG decoding, PCIe traffic and
+// the kernels overlap; the calling thread only issues work and hands finished batches to the callback. It replaces cv::imread + cvtColor of
+// ./cimbar's loop (/root/reference/src/exe/cimbar/cimbar.cpp:124-162), which decodes one file at a time on one thread.
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/cimbar_ingest.h"
+
+namespace {
+
+constexpr size_t FRAME = (size_t)CIMBAR_HIP_FRAME_DIM * CIMBAR_HIP_FRAME_DIM * 3;
+
+// ---------------------------------------------------------------------------------------------------------------- PNG
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c)
+{
+	const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+	return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// PNG (ISO/IEC 15948): signature, IHDR, [PLTE], IDAT..., IEND; zlib stream of filtered scanlines. Output: RGB8, alpha dropped, gray
+// replicated, 16-bit samples reduced to their high byte -- what cv::imread(IMREAD_COLOR) followed by BGR2RGB gives the reference.
+int png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t cap, unsigned* pw, unsigned* ph, std::vector<uint8_t>& idat, std::vector<uint8_t>& raw)
+{
+	static const uint8_t SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	if (len < 8 + 25 || std::memcmp(png, SIG, 8) != 0) return CIMBAR_INGEST_EFORMAT;
+	size_t pos = 8;
+	unsigned w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+	uint8_t pal[256][3];
+	unsigned npal = 0;
+	bool have_ihdr = false;
+	idat.clear();
+	while (pos + 12 <= len) {
+		const uint32_t clen = be32(png + pos);
+		const uint8_t* tag = png + pos + 4;
+		const uint8_t* data = png + pos + 8;
+		if ((size_t)clen > len - pos - 12) return CIMBAR_INGEST_EFORMAT;
+		if (!std::memcmp(tag, "IHDR", 4)) {
+			if (clen != 13) return CIMBAR_INGEST_EFORMAT;
+			w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+			have_ihdr = true;
+		} else if (!std::memcmp(tag, "PLTE", 4)) {
+			npal = clen / 3 > 256 ? 256 : clen / 3;
+			for (unsigned i = 0; i < npal; ++i) { pal[i][0] = data[3 * i]; pal[i][1] = data[3 * i + 1]; pal[i][2] = data[3 * i + 2]; }
+		} else if (!std::memcmp(tag, "IDAT", 4)) {
+			idat.insert(idat.end(), data, data + clen);
+		} else if (!std::memcmp(tag, "IEND", 4)) {
+			break;
+		}
+		pos += 12 + (size_t)clen;
+	}
+	if (!have_ihdr || w == 0 || h == 0 || w > 32768 || h > 32768) return CIMBAR_INGEST_EFORMAT;
+	if (pw) *pw = w;
+	if (ph) *ph = h;
+	if (interlace != 0) return CIMBAR_INGEST_EFORMAT;
+	unsigned channels;
+	switch (ctype) {
+		case 0: channels = 1; break;
+		case 2: channels = 3; break;
+		case 3: channels = 1; break;
+		case 4: channels = 2; break;
+		case 6: channels = 4; break;
+		default: return CIMBAR_INGEST_EFORMAT;
+	}
+	if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return CIMBAR_INGEST_EFORMAT;
+	if (ctype == 3 && depth == 16) return CIMBAR_INGEST_EFORMAT;
+	if (!rgb) return 0;
+	if (cap < (size_t)w * h * 3) return CIMBAR_HIP_EINVAL;
+	const size_t bits_pp = (size_t)channels * depth, row_bytes = (w * bits_pp + 7) / 8, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+	raw.resize((row_bytes + 1) * (size_t)h);
+	uLongf out_len = (uLongf)raw.size();
+	if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return CIMBAR_INGEST_EFORMAT;
+	// un-filter in place (filter type byte in front of every scanline)
+	for (unsigned y = 0; y < h; ++y) {
+		uint8_t* cur = raw.data() + (row_bytes + 1) * (size_t)y + 1;
+		const uint8_t* up = y ? cur - (row_bytes + 1) : nullptr;
+		switch (cur[-1]) {
+			case 0: break;
+			case 1: for (size_t i = bpp; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+			case 2: if (up) for (size_t i = 0; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+			case 3:
+				for (size_t i = 0; i < row_bytes; ++i) {
+					const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+					cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+				}
+				break;
+			case 4:
+				for (size_t i = 0; i < row_bytes; ++i) {
+					const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+					cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+				}
+				break;
+			default: return CIMBAR_INGEST_EFORMAT;
+		}
+		uint8_t* dst = rgb + (size_t)y * w * 3;
+		if (depth == 8 && ctype == 2) { std::memcpy(dst, cur, (size_t)w * 3); continue; }
+		for (unsigned x = 0; x < w; ++x) {
+			unsigned s[4] = {0, 0, 0, 0};
+			if (depth == 8) for (unsigned c = 0; c < channels; ++c) s[c] = cur[(size_t)x * channels + c];
+			else if (depth == 16) for (unsigned c = 0; c < channels; ++c) s[c] = cur[((size_t)x * channels + c) * 2];
+			else {
+				const unsigned per = 8 / depth, v = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1u << depth) - 1u);
+				s[0] = ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+			}
+			if (ctype == 3) { const unsigned i = s[0] < npal ? s[0] : 0; dst[3 * x] = pal[i][0]; dst[3 * x + 1] = pal[i][1]; dst[3 * x + 2] = pal[i][2]; }
+			else if (ctype == 0 || ctype == 4) { dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = (uint8_t)s[0]; }
+			else { dst[3 * x] = (uint8_t)s[0]; dst[3 * x + 1] = (uint8_t)s[1]; dst[3 * x + 2] = (uint8_t)s[2]; }
+		}
+	}
+	return 0;
+}
+
+bool read_file(const char* path, std::vector<uint8_t>& out)
+{
+	FILE* f = std::fopen(path, "rb");
+	if (!f) return false;
+	std::fseek(f, 0, SEEK_END);
+	const long n = std::ftell(f);
+	std::fseek(f, 0, SEEK_SET);
+	if (n <= 0) { std::fclose(f); return false; }
+	out.resize((size_t)n);
+	const bool ok = std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+	std::fclose(f);
+	return ok;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- pipeline
+struct cimbar_ingest {
+	cimbar_hip_ctx* ctx = nullptr;
+	int device = 0, threads = 1, B = 64, R = 3;
+	std::string err;
+	struct Slot {
+		uint8_t* h_in = nullptr; uint8_t* d_in = nullptr;
+		uint8_t* h_chunks = nullptr; uint8_t* d_chunks = nullptr;
+		uint32_t* h_masks = nullptr; uint32_t* d_masks = nullptr;
+		hipEvent_t done = nullptr;
+		std::vector<uint8_t> valid;
+	};
+	std::vector<Slot> slots;
+	hipStream_t copy_stream = nullptr, out_stream = nullptr;
+	double t_wall = 0, t_host = 0, t_wait = 0;
+};
+
+namespace {
+
+#define ICHK(call)                                                                       \
+	do {                                                                                 \
+		hipError_t e__ = (call);                                                         \
+		if (e__ != hipSuccess) {                                                         \
+			ing->err = std::string(#call) + ": " + hipGetErrorString(e__);              \
+			return CIMBAR_HIP_EHIP;                                                      \
+		}                                                                                \
+	} while (0)
+
+// fill(i, dst) produces frame i into dst (pinned memory) and says whether it is a usable frame
+template <typename FILL>
+int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_sink_fn sink, void* user, FILL fill)
+{
+	if (n <= 0) return 0;
+	ICHK(hipSetDevice(ing->device));
+	const int B = ing->B, R = ing->R, nbatch = (n + B - 1) / B;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<int> filled((size_t)nbatch, 0);      // frames of batch k staged so far
+	std::vector<int> freed((size_t)R, 0);            // how many times slot s has been handed back
+	std::atomic<int> next{0};
+	std::atomic<bool> stop{false};
+	double host_s = 0;
+
+	auto worker = [&]() {
+		double mine = 0;
+		for (;;) {
+			const int i = next.fetch_add(1);
+			if (i >= n || stop.load()) break;
+			const int k = i / B, s = k % R;
+			{
+				std::unique_lock<std::mutex> lk(mu);     // the slot's previous batch (k - R) must have been consumed
+				cv.wait(lk, [&] { return freed[s] >= k / R || stop.load(); });
+			}
+			if (stop.load()) break;
+			const double t0 = now_s();
+			const bool ok = fill(i, ing->slots[s].h_in + (size_t)(i - k * B) * FRAME);
+			ing->slots[s].valid[(size_t)(i - k * B)] = ok ? 1 : 0;
+			mine += now_s() - t0;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				filled[(size_t)k] += 1;
+			}
+			cv.notify_all();
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		host_s += mine;
+	};
+	std::vector<std::thread> pool;
+	const int nthreads = ing->threads < n ? ing->threads : n;
+	for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+
+	int64_t total = 0;
+	int rc = 0;
+	double wait_s = 0;
+	const double t_start = now_s();
+	auto consume = [&](int k) -> int {
+		cimbar_ingest::Slot& sl = ing->slots[(size_t)(k % R)];
+		const int m = (k == nbatch - 1) ? n - k * B : B;
+		const double t0 = now_s();
+		hipError_t e = hipEventSynchronize(sl.done);
+		wait_s += now_s() - t0;
+		if (e != hipSuccess) { ing->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return CIMBAR_HIP_EHIP; }
+		for (int j = 0; j < m; ++j) {
+			if (!sl.valid[(size_t)j]) { sl.h_masks[j] = 0; std::memset(sl.h_chunks + (size_t)j * CIMBAR_HIP_FRAME_BYTES, 0, CIMBAR_HIP_FRAME_BYTES); }
+			total += (int64_t)CIMBAR_HIP_CHUNK_SIZE * __builtin_popcount(sl.h_masks[j] & 0xFFFu);
+		}
+		const int stop_now = sink ? sink(user, sl.h_chunks, sl.h_masks, k * B, m) : 0;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			freed[(size_t)(k % R)] += 1;
+		}
+		cv.notify_all();
+		return stop_now ? 1 : 0;
+	};
+	int consumed = 0;
+	for (int k = 0; k < nbatch && rc == 0; ++k) {
+		cimbar_ingest::Slot& sl = ing->slots[(size_t)(k % R)];
+		const int m = (k == nbatch - 1) ? n - k * B : B;
+		{
+			const double t0 = now_s();
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return filled[(size_t)k] == m; });
+			(void)t0;
+		}
+		hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, (size_t)m * FRAME, hipMemcpyHostToDevice, ing->copy_stream);
+		if (e != hipSuccess) { ing->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
+		// "the frames are whatever hip_stream has produced up to here": the library's own stream waits for the copy
+		int r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, ing->copy_stream);
+		if (r == 0) r = cimbar_hip_pipeline_wait(ing->ctx, ing->out_stream, 0);
+		if (r != 0) { ing->err = std::string("decode: ") + cimbar_hip_last_error(ing->ctx); rc = r; break; }
+		(void)hipMemcpyAsync(sl.h_chunks, sl.d_chunks, (size_t)m * CIMBAR_HIP_FRAME_BYTES, hipMemcpyDeviceToHost, ing->out_stream);
+		(void)hipMemcpyAsync(sl.h_masks, sl.d_masks, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, ing->out_stream);
+		(void)hipEventRecord(sl.done, ing->out_stream);
+		// keep R - 1 batches in flight behind the one just issued
+		while (consumed <= k - (R - 1) && rc == 0) {
+			const int c = consume(consumed++);
+			if (c < 0) rc = c;
+			else if (c > 0) { rc = 1; }
+		}
+	}
+	while (consumed < nbatch && rc == 0) {
+		// (only batches that were issued can be consumed; an early stop leaves the rest)
+		const int c = consume(consumed++);
+		if (c < 0) rc = c;
+		else if (c > 0) rc = 1;
+	}
+	stop.store(true);
+	cv.notify_all();
+	for (auto& t : pool) t.join();
+	(void)hipStreamSynchronize(ing->copy_stream);
+	(void)hipStreamSynchronize(ing->out_stream);
+	(void)cimbar_hip_pipeline_wait(ing->ctx, ing->out_stream, 0);
+	(void)hipStreamSynchronize(ing->out_stream);
+	ing->t_wall = now_s() - t_start;
+	ing->t_host = host_s;
+	ing->t_wait = wait_s;
+	return rc < 0 ? rc : total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height)
+{
+	if (!png) return CIMBAR_HIP_EINVAL;
+	std::vector<uint8_t> idat, raw;
+	return png_decode(png, len, rgb, rgb_capacity, width, height, idat, raw);
+}
+
+int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out)
+{
+	if (!ctx || !out) return CIMBAR_HIP_EINVAL;
+	*out = nullptr;
+	cimbar_ingest* ing = new cimbar_ingest();
+	ing->ctx = ctx;
+	ing->device = cimbar_hip_device(ctx);
+	int hw = (int)std::thread::hardware_concurrency();
+	if (hw <= 0) hw = 8;
+	ing->threads = threads > 0 ? threads : (hw > 64 ? 64 : hw);
+	ing->B = batch_frames > 0 ? batch_frames : 64;
+	const int depth = cimbar_hip_pipeline_depth(ctx);
+	ing->R = ring > 0 ? ring : 3;
+	if (ing->R < 2) ing->R = 2;
+	if (ing->R > depth) ing->R = depth;
+	auto fail = [&](const char* what) { ing->err = what; cimbar_ingest_destroy(ing); return CIMBAR_HIP_ENOMEM; };
+	if (hipSetDevice(ing->device) != hipSuccess) return fail("hipSetDevice");
+	if (hipStreamCreateWithFlags(&ing->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+	if (hipStreamCreateWithFlags(&ing->out_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+	ing->slots.resize((size_t)ing->R);
+	for (auto& s : ing->slots) {
+		const size_t nb = (size_t)ing->B;
+		if (hipHostMalloc((void**)&s.h_in, nb * FRAME, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
+		if (hipMalloc((void**)&s.d_in, nb * FRAME) != hipSuccess) return fail("device input");
+		if (hipHostMalloc((void**)&s.h_chunks, nb * CIMBAR_HIP_FRAME_BYTES, hipHostMallocDefault) != hipSuccess) return fail("pinned chunks");
+		if (hipMalloc((void**)&s.d_chunks, nb * CIMBAR_HIP_FRAME_BYTES) != hipSuccess) return fail("device chunks");
+		if (hipHostMalloc((void**)&s.h_masks, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail("pinned masks");
+		if (hipMalloc((void**)&s.d_masks, nb * sizeof(uint32_t)) != hipSuccess) return fail("device masks");
+		if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail("event");
+		s.valid.assign(nb, 0);
+	}
+	*out = ing;
+	return 0;
+}
+
+void cimbar_ingest_destroy(cimbar_ingest* ing)
+{
+	if (!ing) return;
+	(void)hipSetDevice(ing->device);
+	for (auto& s : ing->slots) {
+		if (s.h_in) (void)hipHostFree(s.h_in);
+		if (s.d_in) (void)hipFree(s.d_in);
+		if (s.h_chunks) (void)hipHostFree(s.h_chunks);
+		if (s.d_chunks) (void)hipFree(s.d_chunks);
+		if (s.h_masks) (void)hipHostFree(s.h_masks);
+		if (s.d_masks) (void)hipFree(s.d_masks);
+		if (s.done) (void)hipEventDestroy(s.done);
+	}
+	if (ing->copy_stream) (void)hipStreamDestroy(ing->copy_stream);
+	if (ing->out_stream) (void)hipStreamDestroy(ing->out_stream);
+	delete ing;
+}
+
+const char* cimbar_ingest_last_error(const cimbar_ingest* ing) { return ing ? ing->err.c_str() : "null"; }
+
+int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, int nfiles, int should_preprocess, int color_correction,
+                                cimbar_ingest_sink_fn sink, void* user)
+{
+	if (!ing || !paths || nfiles < 0) return CIMBAR_HIP_EINVAL;
+	auto fill = [&](int i, uint8_t* dst) -> bool {
+		thread_local std::vector<uint8_t> file, idat, raw;
+		if (!read_file(paths[i], file)) return false;
+		unsigned w = 0, h = 0;
+		if (png_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0) return false;
+		if (w != (unsigned)CIMBAR_HIP_FRAME_DIM || h != (unsigned)CIMBAR_HIP_FRAME_DIM) return false;   // (larger, padded frames: not supported on this path)
+		return png_decode(file.data(), file.size(), dst, FRAME, &w, &h, idat, raw) == 0;
+	};
+	return run_pipeline(ing, nfiles, should_preprocess, color_correction, sink, user, fill);
+}
+
+int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, int should_preprocess, int color_correction,
+                              cimbar_ingest_sink_fn sink, void* user)
+{
+	if (!ing || !frames || n < 0) return CIMBAR_HIP_EINVAL;
+	auto fill = [&](int i, uint8_t* dst) -> bool { std::memcpy(dst, frames + (size_t)i * FRAME, FRAME); return true; };
+	return run_pipeline(ing, n, should_preprocess, color_correction, sink, user, fill);
+}
+
+int cimbar_ingest_timings(const cimbar_ingest* ing, double out3[3])
+{
+	if (!ing || !out3) return CIMBAR_HIP_EINVAL;
+	out3[0] = ing->t_wall; out3[1] = ing->t_host; out3[2] = ing->t_wait;
+	return 0;
+}
+
+}  // extern "C"

@@ -27,7 +27,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
-    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks",
+    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device",
 )
 
 
@@ -89,6 +89,8 @@ def load_library(path=None):
     lib.cimbar_hip_comm_destroy.restype = None
     lib.cimbar_hip_gather_chunks.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.cimbar_hip_gather_chunks.restype = i32
+    lib.cimbar_hip_device.argtypes = [vp]
+    lib.cimbar_hip_device.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]

@@ -1,0 +1,117 @@
+"""ctypes binding of include/cimbar_ingest.h (libcimbar_ingest.so): PNG decode pool + pinned ring + overlapped H2D in front of the device
+decode path. Plumbing for tests / bench.py, like decoder.py."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import decoder, modeb
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcimbar_ingest.so")
+EXPORTS = ("cimbar_png_decode", "cimbar_ingest_create", "cimbar_ingest_destroy", "cimbar_ingest_last_error", "cimbar_ingest_run_files",
+           "cimbar_ingest_run_raw", "cimbar_ingest_timings")
+SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int)
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise decoder.CimbarHipError(f"{LIB_PATH} not found: build it with `python -m libcimbar_amd.build`")
+        decoder.load_library()
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.cimbar_png_decode.argtypes = [vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+        L.cimbar_png_decode.restype = i32
+        L.cimbar_ingest_create.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+        L.cimbar_ingest_create.restype = i32
+        L.cimbar_ingest_destroy.argtypes = [vp]
+        L.cimbar_ingest_destroy.restype = None
+        L.cimbar_ingest_last_error.argtypes = [vp]
+        L.cimbar_ingest_last_error.restype = ctypes.c_char_p
+        L.cimbar_ingest_run_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, i32, i32, SINK_FN, vp]
+        L.cimbar_ingest_run_files.restype = ctypes.c_int64
+        L.cimbar_ingest_run_raw.argtypes = [vp, vp, i32, i32, i32, SINK_FN, vp]
+        L.cimbar_ingest_run_raw.restype = ctypes.c_int64
+        L.cimbar_ingest_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+        L.cimbar_ingest_timings.restype = i32
+        _lib = L
+    return _lib
+
+
+def png_decode(data):
+    """PNG bytes -> (h, w, 3) uint8 RGB, as cv::imread + BGR2RGB would hand it to the decoder"""
+    L = load_library()
+    buf = np.frombuffer(data, np.uint8)
+    w, h = ctypes.c_uint(0), ctypes.c_uint(0)
+    rc = L.cimbar_png_decode(buf.ctypes.data, buf.size, None, 0, ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        raise decoder.CimbarHipError(f"cimbar_png_decode: {rc}")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    rc = L.cimbar_png_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size, ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        raise decoder.CimbarHipError(f"cimbar_png_decode: {rc}")
+    return out
+
+
+class Ingest:
+    def __init__(self, dec, threads=0, batch_frames=64, ring=3):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.cimbar_ingest_create(dec._ctx, int(threads), int(batch_frames), int(ring), ctypes.byref(self._h))
+        if rc != 0:
+            raise decoder.CimbarHipError(f"cimbar_ingest_create: {rc}")
+        self._dec = dec
+
+    def close(self):
+        if self._h:
+            self._lib.cimbar_ingest_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def _collect(self, n):
+        chunks = np.zeros((n, modeb.FRAME_BYTES), np.uint8)
+        masks = np.zeros(n, np.uint32)
+
+        def cb(user, c, m, first, cnt):
+            chunks[first:first + cnt] = np.ctypeslib.as_array(c, shape=(cnt, modeb.FRAME_BYTES))
+            masks[first:first + cnt] = np.ctypeslib.as_array(m, shape=(cnt,))
+            return 0
+        return chunks, masks, SINK_FN(cb)
+
+    def run_files(self, paths, should_preprocess=False, color_correction=2):
+        n = len(paths)
+        chunks, masks, cb = self._collect(n)
+        arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        rc = self._lib.cimbar_ingest_run_files(self._h, arr, n, int(bool(should_preprocess)), int(color_correction), cb, None)
+        if rc < 0:
+            raise decoder.CimbarHipError(f"cimbar_ingest_run_files: {rc} {self._lib.cimbar_ingest_last_error(self._h).decode()}")
+        return int(rc), chunks, masks
+
+    def run_raw(self, frames, should_preprocess=False, color_correction=2, collect=True):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8) if not isinstance(frames, int) else frames
+        n = frames.shape[0]
+        if collect:
+            chunks, masks, cb = self._collect(n)
+        else:
+            chunks = masks = None
+            cb = SINK_FN(lambda user, c, m, first, cnt: 0)
+        rc = self._lib.cimbar_ingest_run_raw(self._h, frames.ctypes.data, n, int(bool(should_preprocess)), int(color_correction), cb, None)
+        if rc < 0:
+            raise decoder.CimbarHipError(f"cimbar_ingest_run_raw: {rc} {self._lib.cimbar_ingest_last_error(self._h).decode()}")
+        return int(rc), chunks, masks
+
+    def run_raw_ptr(self, ptr, n, should_preprocess=False, color_correction=2):
+        """frames at a raw host address (e.g. a pinned torch tensor); results discarded, returns good bytes"""
+        cb = SINK_FN(lambda user, c, m, first, cnt: 0)
+        rc = self._lib.cimbar_ingest_run_raw(self._h, ctypes.c_void_p(ptr), int(n), int(bool(should_preprocess)), int(color_correction), cb, None)
+        if rc < 0:
+            raise decoder.CimbarHipError(f"cimbar_ingest_run_raw: {rc} {self._lib.cimbar_ingest_last_error(self._h).decode()}")
+        return int(rc)
+
+    def timings(self):
+        out = (ctypes.c_double * 3)()
+        self._lib.cimbar_ingest_timings(self._h, out)
+        return {"wall_s": out[0], "host_fill_s": out[1], "device_wait_s": out[2]}
