@@ -19,7 +19,7 @@ Extra objects in that line:
   extra         N = 1 only: BASELINE configs[2] (99 substituted cells per frame), host-fed decode (pinned host frames in,
                 H2D inside the timed region), the extractor chain of configs[4] (1080p captures -> scan -> deskew -> decode)
 --config 4 runs BASELINE configs[3] instead (strong scaling: an 8192-frame fountain stream of a 16 MiB file split over the
-ranks, gather, rank-0 wirehair sink fed inside the timed region): see bench_config4().
+ranks, gather, rank-0 wirehair sink fed inside the timed region): see bench_config4.py.
 """
 import argparse
 import hashlib
@@ -300,7 +300,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.config == 4:
-        from libcimbar_amd import config4
+        import bench_config4 as config4
         line = config4.bench(dec, dev, rank, world, args)
         if rank == 0:
             print(json.dumps(line), flush=True)

@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from . import framegen, modeb, multigpu
+from libcimbar_amd import framegen, modeb, multigpu
 
 FILE_SIZE = 16 << 20
 N_FRAMES = 8192

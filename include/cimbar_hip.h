@@ -45,13 +45,22 @@ enum { CIMBAR_HIP_MEM_HOST = 0, CIMBAR_HIP_MEM_DEVICE = 1 };
 
 typedef struct cimbar_hip_ctx cimbar_hip_ctx;
 
-/* cimbard_configure_decode(mode) + `Decoder dec;` : only mode 68 ("B", Conf8x8) is implemented; 0 selects it too
- * (Config::temp_conf default, Config.h:19-44). `device` is a HIP device ordinal. */
+/* cimbard_configure_decode(mode) + `Decoder dec;` (cimbar_recv_js.cpp, Config::update, Config.h:19-50). Modes built: 68 ("B", Conf8x8,
+ * 1024x1024, GridConf.h:121-142; 0 selects it too, Config::temp_conf's default) and 67 ("Bm", Conf8x8_mini, 1024x720, GridConf.h:168-189).
+ * Any other value (4 / 8 legacy, 66 micro) -> CIMBAR_HIP_EINVAL. `device` is a HIP device ordinal. Everywhere below "frame" means an
+ * image_size_x x image_size_y RGB8 image of the context's mode, "12 * 625" the mode's chunks-per-frame * chunk size (12 * 429 in mode 67)
+ * and "60 blocks of 125" its RS layout (36 blocks of 143): cimbar_hip_geometry reports the numbers. */
 int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out);
 void cimbar_hip_destroy(cimbar_hip_ctx* ctx);
 
-/* cimbard_get_bufsize(): bytes of chunk space one frame needs (12 * 625) */
+/* cimbard_get_bufsize(): bytes of chunk space one frame needs in the DEFAULT mode (12 * 625); a context's own is geometry[4] * geometry[5] */
 int cimbar_hip_bufsize(void);
+
+/* The grid a context was created for -- the Config:: getters the reference's callers size their buffers with (Config.h:52-165):
+ * out = {mode, image_size_x, image_size_y, total_cells, fountain_chunks_per_frame, fountain_chunk_size, RS blocks per frame (symbol + colour),
+ *        ecc_block_size, ecc_bytes, cells_per_col_x, cells_per_col_y, cell_offset}. Returns CIMBAR_HIP_GEOMETRY_WORDS. */
+enum { CIMBAR_HIP_GEOMETRY_WORDS = 12 };
+int cimbar_hip_geometry(const cimbar_hip_ctx* ctx, int32_t out[CIMBAR_HIP_GEOMETRY_WORDS]);
 
 /* The 16 symbol-tile hashes as cimbar_hip_create computes them from the embedded tile bitmaps -- what CimbDecoder's constructor does
  * (CimbDecoder.cpp:58-66,87-99: getTile -> average_hash). Host-only arithmetic (works without a device); returns 16. */

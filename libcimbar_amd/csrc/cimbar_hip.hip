@@ -35,58 +35,17 @@
 
 #include "../../include/cimbar_hip.h"
 
-namespace {
+// One copy of the geometry-dependent code per supported mode (Config.h:19-44), then the mode-independent C ABI on top.
+#define CIMBAR_MODE 68
+#define CIMBAR_NS m68
+#include "mode.hip.inc"
+#undef CIMBAR_MODE
+#undef CIMBAR_NS
+#define CIMBAR_MODE 67
+#define CIMBAR_NS m67
+#include "mode.hip.inc"
+#undef CIMBAR_MODE
+#undef CIMBAR_NS
 
-// ------------------------------------------------------------------------------------------------ mode-B constants
-// lib/cimb_translator/GridConf.h:121-142 (Conf8x8); Config.h:101-165
-constexpr int IMG = 1024;
-constexpr int PITCH = 9, OFFSET = 8, DIM = 112, MARKER = 6;
-constexpr int TOP_W = DIM - 2 * MARKER;               // 100
-constexpr int TOP_CELLS = TOP_W * MARKER;             // 600
-constexpr int MID_CELLS = DIM * (DIM - 2 * MARKER);   // 11200
-constexpr int NCELLS = 12400;
-constexpr int RS_BLOCK = 155, RS_PARITY = 30, RS_DATA = 125;
-constexpr int SYM_BLOCKS = 40, COL_BLOCKS = 20, ALL_BLOCKS = 60;
-constexpr int CHUNK = 625, CHUNKS = 12, FRAME_BYTES = CHUNK * CHUNKS;
-constexpr int PLANE_WORDS = IMG * IMG / 32;           // 32768 u32 per frame
-constexpr size_t FRAME_RGB = (size_t)IMG * IMG * 3;
-constexpr int ANCHOR = 30;
-constexpr int HEAP_CAP = 12 * NCELLS + 64;            // <= 12 offers per decoded cell + 8 seeds
-
-// the 16 tile hashes and the exact-match slot table of k_symbols: computed by cimbar_hip_create from the tile bitmaps the way
-// CimbDecoder's constructor does (CimbDecoder.cpp:58-66,87-99 -> Common.cpp:150-171 getTile -> average_hash.h:19-39), see
-// build_tile_hashes() in host.hip.inc
-__constant__ uint64_t c_tile[16];
-
-// Common.cpp:21-31 getColor4 (colour_mode 1)
-__constant__ int c_palette[4][3] = {{0, 255, 0}, {0, 255, 255}, {255, 255, 0}, {255, 0, 255}};
-
-// GF(2^8), primitive poly 0x187 (libcorrect field.h:26-62): exp[512], log[256]
-__constant__ uint8_t c_gf_exp[512];
-__constant__ uint8_t c_gf_log[256];
-
-struct Tables {
-	ushort2* cell_xy;        // [NCELLS] top-left pixel of each cell (CellPositions.cpp:5-51)
-	uint16_t* stream_cell;   // [NCELLS] stream index -> linear cell index (Interleave.h:8-24)
-	uint16_t* cell_grid;     // [NCELLS] grid slot (row * 112 + col) of each cell: where K1 left its 6x6 colour mean
-	uint16_t* ccm_grid;      // [96] grid slot (row * 112 + col) of the cells whose colour the fountain header predicts: colour-stream
-	                         // cells 3100*c + t, t < 24 (CimbReader.cpp:188-227)
-	int16_t* cand;           // [NCELLS][12] the cells FloodDecodePositions::update may offer to, in its order: right, left, bottom,
-	                         // top (AdjacentCellFinder.cpp:16-105), then the 4 horizontal and 4 vertical "horizon" cells
-	                         // (FloodDecodePositions.cpp:93-129); -1 = none
-};
-
-#include "k1_threshold.hip.inc"
-#include "k2_symbols.hip.inc"
-#include "k2b_flood.hip.inc"
-#include "k2c_floodwave.hip.inc"
-#include "k3_rs.hip.inc"
-#include "k4_frame.hip.inc"
-#include "encode.hip.inc"
-#include "extract.hip.inc"
-#include "scan.hip.inc"
-
-}  // namespace
-
-#include "host.hip.inc"
+#include "api.hip.inc"
 #include "comm.hip.inc"

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from . import modeb
+from . import geometry
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_hip.so")
@@ -27,7 +27,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
-    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device",
+    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
 )
 
 
@@ -55,6 +55,8 @@ def load_library(path=None):
     lib.cimbar_hip_destroy.restype = None
     lib.cimbar_hip_bufsize.argtypes = []
     lib.cimbar_hip_bufsize.restype = i32
+    lib.cimbar_hip_geometry.argtypes = [vp, vp]
+    lib.cimbar_hip_geometry.restype = i32
     lib.cimbar_hip_tile_hashes.argtypes = [vp]
     lib.cimbar_hip_tile_hashes.restype = i32
     lib.cimbar_hip_last_error.argtypes = [vp]
@@ -145,6 +147,12 @@ class HipDecoder:
             raise CimbarHipError(f"cimbar_hip_create(device={device}, mode={mode}) failed: {_ERR.get(rc, rc)} "
                                  "(a gfx950 GPU is required; there is no CPU fallback)")
         self.device = device
+        g = (ctypes.c_int32 * 12)()
+        self._check(self._lib.cimbar_hip_geometry(self._ctx, g), "cimbar_hip_geometry")
+        self.geo = geometry.for_mode(g[0])
+        if (self.geo.IMG_W, self.geo.IMG_H, self.geo.NCELLS, self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK, self.geo.BLOCKS, self.geo.RS_BLOCK,
+                self.geo.RS_PARITY, self.geo.DIM_X, self.geo.DIM_Y, self.geo.OFFSET) != tuple(g[1:12]):
+            raise CimbarHipError(f"library geometry {list(g)} does not match libcimbar_amd.geometry for mode {g[0]}")
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -169,7 +177,7 @@ class HipDecoder:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         if rgb.ndim != 3 or rgb.shape[2] != 3:
             raise CimbarHipError("decode_frame: expected an HxWx3 uint8 image")
-        chunks = np.zeros((modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        chunks = np.zeros((self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK), dtype=np.uint8)
         mask = ctypes.c_uint32(0)
         rc = self._lib.cimbar_hip_decode_frame(self._ctx, rgb.ctypes.data, rgb.shape[1], rgb.shape[0], rgb.strides[0],
                                                int(bool(should_preprocess)), int(color_correction), chunks.ctypes.data,
@@ -181,9 +189,9 @@ class HipDecoder:
         """frames: (n,1024,1024,3) uint8 numpy. Returns (total_good_bytes, chunks (n,12,625), masks (n,) uint32)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n = frames.shape[0]
-        if frames.shape[1:] != (modeb.IMG, modeb.IMG, 3):
+        if frames.shape[1:] != self.geo.FRAME_SHAPE:
             raise CimbarHipError("decode_batch: frames must be (n,1024,1024,3) uint8")
-        chunks = np.zeros((n, modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        chunks = np.zeros((n, self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK), dtype=np.uint8)
         masks = np.zeros(n, dtype=np.uint32)
         rc = self._lib.cimbar_hip_decode_batch(self._ctx, frames.ctypes.data, n, MEM_HOST, int(bool(should_preprocess)),
                                                int(color_correction), chunks.ctypes.data, masks.ctypes.data, MEM_HOST, None)
@@ -195,10 +203,10 @@ class HipDecoder:
         data (n,7500) uint8 with failed RS blocks zeroed, block_ok (n,60) uint8)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n = frames.shape[0]
-        if frames.shape[1:] != (modeb.IMG, modeb.IMG, 3):
+        if frames.shape[1:] != self.geo.FRAME_SHAPE:
             raise CimbarHipError("decode_plain_batch: frames must be (n,1024,1024,3) uint8")
-        data = np.zeros((n, modeb.FRAME_BYTES), dtype=np.uint8)
-        ok = np.zeros((n, 60), dtype=np.uint8)
+        data = np.zeros((n, self.geo.FRAME_BYTES), dtype=np.uint8)
+        ok = np.zeros((n, self.geo.BLOCKS), dtype=np.uint8)
         rc = self._lib.cimbar_hip_decode_plain_batch(self._ctx, frames.ctypes.data, n, MEM_HOST, int(bool(should_preprocess)),
                                                      int(color_correction), data.ctypes.data, ok.ctypes.data, MEM_HOST, None)
         self._check(rc, "cimbar_hip_decode_plain_batch")
@@ -249,7 +257,7 @@ class HipDecoder:
         captures = np.ascontiguousarray(captures, dtype=np.uint8)
         corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
         n, h, w = captures.shape[:3]
-        out = np.zeros((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        out = np.zeros((n, *self.geo.FRAME_SHAPE), dtype=np.uint8)
         self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, corners.ctypes.data, out.ctypes.data,
                                                       MEM_HOST, None), "cimbar_hip_deskew_batch")
         return out
@@ -265,7 +273,7 @@ class HipDecoder:
         """Extractor::extract for captures (n,h,w,3) uint8 numpy -> (status (n,) int32, corners (n,8) float32, frames (n,1024,1024,3))"""
         captures = np.ascontiguousarray(captures, dtype=np.uint8)
         n, h, w = captures.shape[:3]
-        frames = np.zeros((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        frames = np.zeros((n, *self.geo.FRAME_SHAPE), dtype=np.uint8)
         status = np.zeros(n, dtype=np.int32)
         corners = np.zeros((n, 8), dtype=np.float32)
         self._check(self._lib.cimbar_hip_extract_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, frames.ctypes.data, status.ctypes.data,
@@ -276,7 +284,7 @@ class HipDecoder:
         """cimbard_scan_extract_decode for captures (n,h,w,3) uint8 numpy -> (good_bytes, chunks (n,12,625), masks (n,), status (n,))"""
         captures = np.ascontiguousarray(captures, dtype=np.uint8)
         n, h, w = captures.shape[:3]
-        chunks = np.zeros((n, modeb.CHUNKS_PER_FRAME, modeb.CHUNK), dtype=np.uint8)
+        chunks = np.zeros((n, self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK), dtype=np.uint8)
         masks = np.zeros(n, dtype=np.uint32)
         status = np.zeros(n, dtype=np.int32)
         rc = self._check(self._lib.cimbar_hip_scan_extract_decode_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, int(preprocess),
@@ -298,10 +306,10 @@ class HipDecoder:
         Like the reference, a sink whose chunk_size() is not 625 gets nothing written but the byte count is still returned."""
         good, chunks, mask = self.decode_frame(img, should_preprocess, color_correction)
         feed = True
-        if hasattr(ostream, "chunk_size") and ostream.chunk_size() != modeb.CHUNK:
+        if hasattr(ostream, "chunk_size") and ostream.chunk_size() != self.geo.CHUNK:
             feed = False
         if feed:
-            for j in range(modeb.CHUNKS_PER_FRAME):
+            for j in range(self.geo.CHUNKS_PER_FRAME):
                 if mask & (1 << j):
                     ostream.write(chunks[j].tobytes())
         return good
@@ -310,9 +318,9 @@ class HipDecoder:
     def _ensure_template(self):
         if getattr(self, "_have_template", False):
             return
-        path = os.path.join(_HERE, "data", "modeb_template.npz")
+        path = os.path.join(_HERE, "data", self.geo.TEMPLATE)
         z = np.load(path)
-        t = np.zeros(modeb.FRAME_RGB_BYTES, dtype=np.uint8)
+        t = np.zeros(self.geo.FRAME_RGB_BYTES, dtype=np.uint8)
         t[z["idx"]] = z["val"]
         self._check(self._lib.cimbar_hip_set_template(self._ctx, t.ctypes.data, MEM_HOST), "cimbar_hip_set_template")
         self._have_template = True
@@ -320,9 +328,9 @@ class HipDecoder:
     def encode_batch(self, payload):
         """payload (n,7500) uint8 numpy -> frames (n,1024,1024,3) uint8 numpy (Encoder::encode_next for n frames)."""
         self._ensure_template()
-        payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(-1, modeb.FRAME_BYTES)
+        payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(-1, self.geo.FRAME_BYTES)
         n = payload.shape[0]
-        out = np.empty((n, modeb.IMG, modeb.IMG, 3), dtype=np.uint8)
+        out = np.empty((n, *self.geo.FRAME_SHAPE), dtype=np.uint8)
         self._check(self._lib.cimbar_hip_encode_batch(self._ctx, payload.ctypes.data, n, MEM_HOST, out.ctypes.data, MEM_HOST, None),
                     "cimbar_hip_encode_batch")
         return out
@@ -359,9 +367,9 @@ class HipDecoder:
 
     def tap(self, what, n):
         shapes = {
-            TAP_BITPLANE: ((n, modeb.IMG * modeb.IMG // 8), np.uint8), TAP_SYMBOLS: ((n, modeb.NCELLS), np.uint8),
-            TAP_COLORS: ((n, modeb.NCELLS), np.uint8), TAP_DRIFT: ((n, modeb.NCELLS, 2), np.int8),
-            TAP_RS_OK: ((n, 60), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8),
+            TAP_BITPLANE: ((n, self.geo.IMG_W * self.geo.IMG_H // 8), np.uint8), TAP_SYMBOLS: ((n, self.geo.NCELLS), np.uint8),
+            TAP_COLORS: ((n, self.geo.NCELLS), np.uint8), TAP_DRIFT: ((n, self.geo.NCELLS, 2), np.int8),
+            TAP_RS_OK: ((n, self.geo.BLOCKS), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8),
         }
         shape, dt = shapes[what]
         out = np.zeros(shape, dtype=dt)

@@ -15,10 +15,10 @@
 /* ------------------------------------------------------------------------------------------------ mode B constants
  * lib/cimb_translator/GridConf.h:121-142 (Conf8x8), Config.h:101-165 */
 enum {
-	IMG = CO_IMG, CELL = 8, PITCH = 9, OFFSET = 8, DIM = 112, MARKER = 6, /* lrint(54/9), GridConf.h:32-40 */
-	TOP_W = DIM - 2 * MARKER,           /* 100 */
+	IMG_W = CO_IMG_W, IMG_H = CO_IMG_H, CELL = 8, PITCH = 9, OFFSET = CO_OFFSET, DIM_X = CO_DIM_X, DIM_Y = CO_DIM_Y, MARKER = 6, /* lrint(54/9), GridConf.h:32-40 */
+	TOP_W = DIM_X - 2 * MARKER,         /* 100 */
 	TOP_CELLS = TOP_W * MARKER,         /* 600 */
-	MID_CELLS = DIM * (DIM - 2 * MARKER), /* 11200 */
+	MID_CELLS = DIM_X * (DIM_Y - 2 * MARKER), /* 11200 | 7392 */
 	NCELLS = CO_CELLS,
 	SYM_BYTES = NCELLS * 4 / 8,         /* 6200 */
 	COL_BYTES = NCELLS * 2 / 8,         /* 3100 */
@@ -35,6 +35,11 @@ static const uint64_t TILE_HASH[16] = {
 	0x8181c3c3e7e7e7e7ULL, 0x0000c3e77e3c1800ULL, 0x0c1c387070381c0cULL, 0x1e1e38381c1c7878ULL
 };
 
+void co_geometry(int32_t o[10])
+{
+	o[0] = CO_MODE; o[1] = IMG_W; o[2] = IMG_H; o[3] = NCELLS; o[4] = CO_CHUNK; o[5] = CO_RS_BLOCK; o[6] = CO_RS_PARITY; o[7] = DIM_X; o[8] = DIM_Y; o[9] = OFFSET;
+}
+
 void co_tile_hashes(uint64_t out16[16]) { memcpy(out16, TILE_HASH, sizeof TILE_HASH); }
 
 /* lib/cimb_translator/Common.cpp:21-31 getColor4 (colour_mode 1, Config.h:61-64) */
@@ -50,12 +55,12 @@ void co_cell_positions(int32_t* xy)
 		xy[2 * n + 1] = (i / TOP_W) * PITCH + OFFSET;
 	}
 	for (int i = 0; i < MID_CELLS; ++i, ++n) {
-		xy[2 * n] = (i % DIM) * PITCH + OFFSET;
-		xy[2 * n + 1] = (i / DIM) * PITCH + MARKER * PITCH + OFFSET;
+		xy[2 * n] = (i % DIM_X) * PITCH + OFFSET;
+		xy[2 * n + 1] = (i / DIM_X) * PITCH + MARKER * PITCH + OFFSET;
 	}
 	for (int i = 0; i < TOP_CELLS; ++i, ++n) {
 		xy[2 * n] = (i % TOP_W) * PITCH + PITCH * MARKER + OFFSET;
-		xy[2 * n + 1] = (i / TOP_W) * PITCH + (DIM - MARKER) * PITCH + OFFSET;
+		xy[2 * n + 1] = (i / TOP_W) * PITCH + (DIM_Y - MARKER) * PITCH + OFFSET;
 	}
 }
 
@@ -97,7 +102,7 @@ static int adj_left(int index)
 static int adj_bottom(int index)
 {
 	if (index < 0 || index >= NCELLS) return -1;
-	int inc = DIM;
+	int inc = DIM_X;
 	if (in_row_with_margin(index)) inc -= MARKER;
 	int next = index + inc;
 	if (in_row_with_margin(next)) next -= MARKER;
@@ -107,7 +112,7 @@ static int adj_bottom(int index)
 }
 static int adj_top(int index)
 {
-	int inc = DIM;
+	int inc = DIM_X;
 	if (in_row_with_margin(index)) inc -= MARKER;
 	int next = index - inc;
 	if (in_row_with_margin(next)) next += MARKER;
@@ -199,7 +204,7 @@ static unsigned bits_read(const uint8_t* buf, size_t index, int length)
 static void window_hashes(const uint8_t* bitplane, int x0, int y0, uint64_t out9[9])
 {
 	unsigned rows[10];
-	for (int i = 0; i < 10; ++i) rows[i] = bits_read(bitplane, (size_t)x0 + (size_t)(y0 + i) * IMG, 10);
+	for (int i = 0; i < 10; ++i) rows[i] = bits_read(bitplane, (size_t)x0 + (size_t)(y0 + i) * IMG_W, 10);
 	for (int wnd = 0; wnd < 9; ++wnd) {
 		uint64_t hsh = 0;
 		for (int k = 0; k < 8; ++k) hsh = (hsh << 8) | ((rows[wnd / 3 + k] >> (2 - wnd % 3)) & 0xFFu);
@@ -313,8 +318,8 @@ int co_symbol_pass(const uint8_t* bitplane, int32_t* visit, uint8_t* dist)
 	/* seeds, FloodDecodePositions.cpp:27-41 */
 	uint16_t small_row = TOP_W, last = NCELLS - 1, between = TOP_CELLS;
 	hent seeds[8] = {{0, 0}, {(uint16_t)(small_row - 1), 0}, {last, 0}, {(uint16_t)(last - (small_row - 1)), 0},
-	                 {between, 1}, {(uint16_t)(between + DIM - 1), 1}, {(uint16_t)(last - between), 1},
-	                 {(uint16_t)(last - (between + DIM - 1)), 1}};
+	                 {between, 1}, {(uint16_t)(between + DIM_X - 1), 1}, {(uint16_t)(last - between), 1},
+	                 {(uint16_t)(last - (between + DIM_X - 1)), 1}};
 	for (int s = 0; s < 8; ++s) heap_push(&hp, seeds[s]);
 
 	int count = 0;
@@ -546,7 +551,7 @@ static void cell_mean_rgb(const uint8_t* rgb, int x, int y, int cols, int rows, 
 	uint16_t r = 0, g = 0, b = 0, count = 0;
 	for (int i = 0; i < rows; ++i)
 		for (int j = 0; j < cols; ++j, ++count) {
-			const uint8_t* p = rgb + ((size_t)(y + i) * IMG + (x + j)) * 3;
+			const uint8_t* p = rgb + ((size_t)(y + i) * IMG_W + (x + j)) * 3;
 			r += p[0]; g += p[1]; b += p[2];
 		}
 	if (!count) { out[0] = out[1] = out[2] = 0; return; }
@@ -594,14 +599,14 @@ unsigned co_best_color(float r, float g, float b, const co_ccm* ccm)
 /* lib/cimb_translator/CimbReader.cpp:55-86 calculateWhite (dark): max over three 4x4 anchor-centre means, floor (1,1,1) */
 static void calculate_white(const uint8_t* rgb, float white[3])
 {
-	int tl = ANCHOR - 2, far = IMG - ANCHOR - 2;
-	int ax[3] = {tl, tl, far}, ay[3] = {tl, far, tl};
+	int tl = ANCHOR - 2, right = IMG_W - ANCHOR - 2, bottom = IMG_H - ANCHOR - 2;
+	int ax[3] = {tl, tl, right}, ay[3] = {tl, bottom, tl};
 	white[0] = white[1] = white[2] = 1.0f;
 	for (int a = 0; a < 3; ++a) {
 		double s[3] = {0, 0, 0};
 		for (int i = 0; i < 4; ++i)
 			for (int j = 0; j < 4; ++j) {
-				const uint8_t* p = rgb + ((size_t)(ay[a] + i) * IMG + (ax[a] + j)) * 3;
+				const uint8_t* p = rgb + ((size_t)(ay[a] + i) * IMG_W + (ax[a] + j)) * 3;
 				s[0] += p[0]; s[1] += p[1]; s[2] += p[2];
 			}
 		for (int c = 0; c < 3; ++c) { float v = (float)(s[c] / 16.0); if (v > white[c]) white[c] = v; }
@@ -775,13 +780,13 @@ static void update_metadata(md_state* st, const uint8_t* buff, unsigned len)
 }
 
 /* lib/encoder/aligned_stream.h:8-131 driven by reed_solomon_stream.h:54-77,109-114: one RS block at a time.
- * Blocks are 125 bytes and chunks 625, so a chunk always completes on a block boundary; the literal state machine is
+ * Blocks are 125 (mode 67: 143) bytes and chunks 625 (429), so a chunk always completes on a block boundary; the literal state machine is
  * kept because a bad LAST block of a chunk leaves _badChunk set and makes the NEXT chunk the one that is dropped. */
 typedef struct { unsigned offset; int bad; unsigned total; unsigned nblocks; uint8_t buf[CO_CHUNK]; } aligner_t;
 
 static void aligner_block(aligner_t* al, int ok, const uint8_t* data125, md_state* md, uint8_t* chunks, uint32_t* mask)
 {
-	unsigned chunk_index = al->nblocks / 5;
+	unsigned chunk_index = al->nblocks / (CO_CHUNK / CO_RS_DATA);   /* 5 | 3 blocks per chunk */
 	al->nblocks++;
 	if (!ok) {                                  /* mark_bad_chunk(125), aligned_stream.h:97-104 */
 		al->bad = 1;
@@ -868,7 +873,7 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 	if (!ccm) ccm = &local;
 	memset(outbuf, 0, (size_t)CO_CHUNKS_PER_FRAME * CO_CHUNK);
 	if (good_mask) *good_mask = 0;
-	if (w != IMG || h != IMG) return -1;   /* restatement covers the deskewed 1024x1024 case only */
+	if (w != IMG_W || h != IMG_H) return -1;   /* restatement covers the deskewed image_size_x x image_size_y case only */
 	ensure_pos();
 
 	static uint32_t rev[NCELLS];
@@ -876,8 +881,8 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 	if (!rev_init) { co_interleave_reverse(rev); rev_init = 1; }
 
 	/* CimbReader ctor, CimbReader.cpp:107-126 */
-	uint8_t* bitplane = (uint8_t*)malloc((size_t)IMG * IMG / 8);
-	co_threshold_bitplane(rgb, IMG, IMG, preprocess, bitplane);
+	uint8_t* bitplane = (uint8_t*)malloc((size_t)IMG_W * IMG_H / 8);
+	co_threshold_bitplane(rgb, IMG_W, IMG_H, preprocess, bitplane);
 	if (color_correction == 1) {
 		float white[3];
 		calculate_white(rgb, white);

@@ -20,13 +20,37 @@
 extern "C" {
 #endif
 
-#define CO_IMG 1024
-#define CO_CELLS 12400
-#define CO_CHUNK 625
-#define CO_CHUNKS_PER_FRAME 12
+/* One geometry per build of the oracle (cc -DCO_MODE=67 -> libcimbar_oracle_m67.so), Config.h:19-44 + GridConf.h:121-186:
+ * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"). */
+#ifndef CO_MODE
+#define CO_MODE 68
+#endif
+#if CO_MODE == 68
+#define CO_IMG_W 1024
+#define CO_IMG_H 1024
+#define CO_OFFSET 8
+#define CO_DIM_X 112
+#define CO_DIM_Y 112
 #define CO_RS_BLOCK 155
 #define CO_RS_PARITY 30
-#define CO_RS_DATA 125
+#elif CO_MODE == 67
+#define CO_IMG_W 1024
+#define CO_IMG_H 720
+#define CO_OFFSET 9
+#define CO_DIM_X 112
+#define CO_DIM_Y 78
+#define CO_RS_BLOCK 179
+#define CO_RS_PARITY 36
+#else
+#error "CO_MODE must be 68 or 67"
+#endif
+#define CO_CELLS (CO_DIM_X * CO_DIM_Y - 4 * 6 * 6)               /* 12400 | 8592 */
+#define CO_CHUNKS_PER_FRAME 12
+#define CO_RS_DATA (CO_RS_BLOCK - CO_RS_PARITY)                  /* 125 | 143 */
+#define CO_CHUNK (CO_CELLS * 6 / 8 / CO_RS_BLOCK * CO_RS_DATA / CO_CHUNKS_PER_FRAME)   /* 625 | 429 */
+
+/* the constants above, for the tests: {mode, image w, image h, cells, chunk bytes, RS block, RS parity, cells per row, cell rows, cell offset} */
+void co_geometry(int32_t out10[10]);
 
 /* models the reference's `static thread_local color_correction` (CimbDecoder.cpp:69-73) */
 typedef struct co_ccm { float m[9]; int active; } co_ccm;

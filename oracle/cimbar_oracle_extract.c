@@ -145,11 +145,11 @@ int co_perspective_transform(const float* src8, const float* dst8, double* m9)
 
 void co_deskew_points(float* dst8)
 {
-	const float size = 1024, anchor = 30;   /* Config::image_size_x/y(), Config::anchor_size() for mode B; padding 0 */
+	const float sx = CO_IMG_W, sy = CO_IMG_H, anchor = 30;   /* Config::image_size_x/y(), Config::anchor_size(); padding 0 (Deskewer.h:28-32) */
 	dst8[0] = anchor; dst8[1] = anchor;
-	dst8[2] = size - anchor; dst8[3] = anchor;
-	dst8[4] = anchor; dst8[5] = size - anchor;
-	dst8[6] = size - anchor; dst8[7] = size - anchor;
+	dst8[2] = sx - anchor; dst8[3] = anchor;
+	dst8[4] = anchor; dst8[5] = sy - anchor;
+	dst8[6] = sx - anchor; dst8[7] = sy - anchor;
 }
 
 /* cv::warpPerspective(img, output, transform, output.size(), INTER_LINEAR), Deskewer.h:38  [assumed-OpenCV imgwarp.cpp]:
@@ -205,14 +205,14 @@ int co_warp_perspective(const uint8_t* rgb, int sw, int sh, const double* m9, ui
 	return 0;
 }
 
-/* Deskewer::deskew for mode B (1024x1024 output, anchor 30, padding 0) from the corners Corners::all() would return */
+/* Deskewer::deskew (image_size_x x image_size_y output -- 1024x1024 in mode B --, anchor 30, padding 0) from the corners Corners::all() would return */
 int co_deskew(const uint8_t* rgb, int sw, int sh, const float* corners8, uint8_t* out1024)
 {
 	float dst8[8];
 	double m9[9];
 	co_deskew_points(dst8);
 	co_perspective_transform(corners8, dst8, m9);
-	return co_warp_perspective(rgb, sw, sh, m9, out1024, 1024, 1024);
+	return co_warp_perspective(rgb, sw, sh, m9, out1024, CO_IMG_W, CO_IMG_H);
 }
 
 /* ------------------------------------------------------------------------------------------------ anchor search
@@ -521,7 +521,7 @@ int co_extract(const uint8_t* rgb, int w, int h, uint8_t* out1024, float* corner
 	int granular = 1;
 	for (int k = 0; k < 4; ++k) {
 		const int a = e[k][0], b = e[k][1];
-		if (!(abs(cx[a] - cx[b]) > CO_IMG || abs(cy[a] - cy[b]) > CO_IMG)) granular = 0;
+		if (!(abs(cx[a] - cx[b]) > CO_IMG_W || abs(cy[a] - cy[b]) > CO_IMG_H)) granular = 0;
 	}
 	return granular ? 1 : 2;
 }

@@ -56,7 +56,7 @@ static int seed_prio(int i)
 {
 	const int last = NCELLS - 1;
 	if (i == 0 || i == TOP_W - 1 || i == last || i == last - (TOP_W - 1)) return 0;
-	if (i == TOP_CELLS || i == TOP_CELLS + DIM - 1 || i == last - TOP_CELLS || i == last - (TOP_CELLS + DIM - 1)) return 1;
+	if (i == TOP_CELLS || i == TOP_CELLS + DIM_X - 1 || i == last - TOP_CELLS || i == last - (TOP_CELLS + DIM_X - 1)) return 1;
 	return 0xFE;
 }
 
@@ -96,8 +96,8 @@ int fm_flood(const uint8_t* bitplane, int prefix, uint8_t* sym_out, int32_t* pos
 		heap_t hp = {0, 0, 0};
 		uint16_t small_row = TOP_W, last = NCELLS - 1, between = TOP_CELLS;
 		hent seeds[8] = {{0, 0}, {(uint16_t)(small_row - 1), 0}, {last, 0}, {(uint16_t)(last - (small_row - 1)), 0},
-		                 {between, 1}, {(uint16_t)(between + DIM - 1), 1}, {(uint16_t)(last - between), 1},
-		                 {(uint16_t)(last - (between + DIM - 1)), 1}};
+		                 {between, 1}, {(uint16_t)(between + DIM_X - 1), 1}, {(uint16_t)(last - between), 1},
+		                 {(uint16_t)(last - (between + DIM_X - 1)), 1}};
 		for (int s = 0; s < 8; ++s) heap_push(&hp, seeds[s]);
 		while (decoded < prefix && decoded < NCELLS && hp.n > 0) {
 			hent e = heap_pop(&hp);
@@ -245,8 +245,8 @@ int fm_sets(const uint8_t* bitplane, int prefix, uint8_t* sym_out, int32_t* pos_
 		heap_t hp = {0, 0, 0};
 		uint16_t small_row = TOP_W, last = NCELLS - 1, between = TOP_CELLS;
 		hent seeds[8] = {{0, 0}, {(uint16_t)(small_row - 1), 0}, {last, 0}, {(uint16_t)(last - (small_row - 1)), 0},
-		                 {between, 1}, {(uint16_t)(between + DIM - 1), 1}, {(uint16_t)(last - between), 1},
-		                 {(uint16_t)(last - (between + DIM - 1)), 1}};
+		                 {between, 1}, {(uint16_t)(between + DIM_X - 1), 1}, {(uint16_t)(last - between), 1},
+		                 {(uint16_t)(last - (between + DIM_X - 1)), 1}};
 		for (int s = 0; s < 8; ++s) heap_push(&hp, seeds[s]);
 		while (decoded < prefix && decoded < NCELLS && hp.n > 0) {
 			hent e = heap_pop(&hp);

@@ -1,6 +1,7 @@
 """Regenerates fixtures that need the REFERENCE build (oracle/_ref/libcimbar_ref.so, i.e. /root/reference at build time):
 
-  libcimbar_amd/data/modeb_template.npz   background + anchors + guides of an empty mode-B frame (CimbWriter.cpp:39-77),
+  libcimbar_amd/data/modeb_template.npz   background + anchors + guides of an empty mode-B frame (CimbWriter.cpp:39-77), and
+  libcimbar_amd/data/modebm_template.npz  the same for mode Bm (67, 1024x720),
                                           stored sparse (flat byte index, value) -- input of libcimbar_amd/framegen.py
   tests/golden/*.npz                      see tests/golden/README.md
 
@@ -21,13 +22,15 @@ def main():
     L = ref_lib()
     if L is None:
         raise SystemExit("oracle/_ref/libcimbar_ref.so missing: run `make -C oracle ref` first")
-    t = np.zeros(1024 * 1024 * 3, np.uint8)
-    L.ref_template_frame(P(t))
-    idx = np.nonzero(t)[0].astype(np.uint32)
     os.makedirs(os.path.join(ROOT, "libcimbar_amd", "data"), exist_ok=True)
-    np.savez_compressed(os.path.join(ROOT, "libcimbar_amd", "data", "modeb_template.npz"), idx=idx, val=t[idx])
-    print("template: %d non-zero bytes" % idx.size)
-
+    for mode, (w, h), name in ((68, (1024, 1024), "modeb_template.npz"), (67, (1024, 720), "modebm_template.npz")):
+        L.ref_configure(mode)
+        t = np.zeros(w * h * 3, np.uint8)
+        L.ref_template_frame(P(t))
+        idx = np.nonzero(t)[0].astype(np.uint32)
+        np.savez_compressed(os.path.join(ROOT, "libcimbar_amd", "data", name), idx=idx, val=t[idx])
+        print("template mode %d: %d non-zero bytes" % (mode, idx.size))
+    L.ref_configure(68)
 
 if __name__ == "__main__":
     main()

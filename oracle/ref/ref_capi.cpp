@@ -82,15 +82,16 @@ struct RefDecoder : Decoder
 	using Decoder::Decoder;
 
 	// Decoder::decode_fountain (Decoder.h:171-189), same objects (CimbReader, aligned_stream bound to update_metadata,
-	// do_decode); the tee records which 5-block group each delivered chunk came from.
+	// do_decode); the tee records which group of blocks each delivered chunk came from.
 	unsigned decode_fountain_masked(const cv::Mat& img, chunk_collector& out, std::vector<unsigned>& slots, bool pre, int cc)
 	{
 		CimbReader reader(img, _decoder, cimbar::Config::color_mode(), pre, cc);
 		unsigned chunk_size = cimbar::Config::fountain_chunk_size();
+		const unsigned blocks_per_chunk = chunk_size / (cimbar::Config::ecc_block_size() - cimbar::Config::ecc_bytes());   // 5 (mode B) | 3 (Bm)
 		block_counting_tee* teep = nullptr;
 		auto on_flush = [&](char* buf, size_t len) {
 			reader.update_metadata(buf, len, chunk_size);
-			if (buf != nullptr && len > 0) slots.push_back((teep->blocks - 1) / 5);
+			if (buf != nullptr && len > 0) slots.push_back((teep->blocks - 1) / blocks_per_chunk);
 		};
 		aligned_stream<chunk_collector> aligner(out, out.chunk_size(), 0, on_flush);
 		block_counting_tee tee(aligner);

@@ -2,17 +2,17 @@
 import numpy as np
 import torch
 
-from libcimbar_amd import framegen, modeb
+from libcimbar_amd import framegen
 
 
 def clean_frames(synth, n, seed=1234, **kw):
-    payload = framegen.synth_payload(n, seed=seed, **kw)
+    payload = framegen.synth_payload(n, seed=seed, mode=synth.geo.MODE, **kw)
     frames = synth.frames_from_payload(payload).numpy()
     return payload.numpy(), frames
 
 
 def tile_error_frames(synth, n, seed=1234, n_errors=99):
-    payload = framegen.synth_payload(n, seed=seed)
+    payload = framegen.synth_payload(n, seed=seed, mode=synth.geo.MODE)
     tiles = synth.cell_tiles(payload)
     bad = framegen.inject_cell_errors(tiles, n_errors=n_errors, seed=5678)
     return payload.numpy(), synth.render(bad).numpy()
@@ -30,10 +30,10 @@ def shift(frame, dy, dx):
 def rescale(frame, grow):
     """grow the image by `grow` pixels and crop the centre: cells drift progressively away from the grid."""
     from PIL import Image
-    n = modeb.IMG + grow
-    im = Image.fromarray(frame).resize((n, n), Image.BILINEAR)
+    h, w = frame.shape[:2]
+    im = Image.fromarray(frame).resize((w + grow, h + grow), Image.BILINEAR)
     o = grow // 2
-    return np.array(im.crop((o, o, o + modeb.IMG, o + modeb.IMG)))
+    return np.array(im.crop((o, o, o + w, o + h)))
 
 
 def blank_region(frame, y0, y1, x0, x1, value=0):
@@ -56,7 +56,7 @@ def distorted_set(synth, seed=77):
         ("rescale+6", rescale(f[3], 6)),
         ("rescale+10", rescale(f[0], 10)),
         ("wipe_band", blank_region(f[1], 300, 420, 0, 1024)),
-        ("wipe_half", blank_region(f[2], 0, 1024, 0, 560, value=255)),
+        ("wipe_half", blank_region(f[2], 0, f[2].shape[0], 0, 560, value=255)),
         ("wipe_corner", blank_region(f[3], 60, 500, 60, 700)),
         ("noise200", add_noise(f[3], 200, 3)),
     ]
@@ -68,11 +68,11 @@ def camera_frame(frame, width=1920, height=1080, quad=((500, 40), (1480, 70), (4
     (top-left, top-right, bottom-left, bottom-right corners in capture pixels) over a flat background -- what the Scanner / Deskewer
     stage in front of the decoder has to undo."""
     from PIL import Image, ImageFilter
-    n = frame.shape[0]
+    fh, fw = frame.shape[:2]
     (x0, y0), (x1, y1), (x2, y2), (x3, y3) = quad
     # PIL wants the map output(x,y) -> input: solve the homography that sends the quad's corners to the frame's corners
     src = [(x0, y0), (x1, y1), (x2, y2), (x3, y3)]
-    dst = [(0, 0), (n, 0), (0, n), (n, n)]
+    dst = [(0, 0), (fw, 0), (0, fh), (fw, fh)]
     A, b = [], []
     for (x, y), (u, v) in zip(src, dst):
         A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)

@@ -96,7 +96,7 @@ def test_bad_arguments_are_refused(hip_decoder):
 
 
 def test_unsupported_modes_and_devices_fail_loudly():
-    for mode in (4, 8, 66, 67, 12345):   # legacy 4/8-colour and the 5x5/Bm/Bu configs are not on the GPU path
+    for mode in (4, 8, 66, 12345):   # legacy 4/8-colour and the micro ("Bu") config are not on the GPU path (67 "Bm" is: test_gpu_mode67.py)
         with pytest.raises(D.CimbarHipError):
             D.HipDecoder(device=0, mode=mode)
     with pytest.raises(D.CimbarHipError):

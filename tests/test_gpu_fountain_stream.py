@@ -78,7 +78,7 @@ def test_library_gather_with_one_rank(hip_decoder):
 def test_bench_config4_small(hip_decoder, ref):
     """bench.py --config 4 at a reduced size on one GPU: slabs through the pipelined entry point, sink fed, file recovered"""
     import argparse
-    from libcimbar_amd import config4
+    import bench_config4 as config4
     dev = torch.device("cuda", 0)
     line = config4.bench(hip_decoder, dev, 0, 1, argparse.Namespace(frames=32, steps=1, warmup=1))
     assert line["chunks_match_encoded_stream"] and line["sink"]["file_recovered_sha256_match"] is True

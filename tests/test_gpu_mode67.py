@@ -1,0 +1,234 @@
+"""GPU: mode 67 ("Bm", Conf8x8_mini: 1024x720 frames, 112x78 cells, RS(179,143), 12 chunks of 429 bytes; GridConf.h:168-189) through the same
+C ABI as mode B -- cimbar_hip_create(device, 67) -- against the oracle built for that mode (oracle/libcimbar_oracle_m67.so, pinned to the
+reference build in tests/test_mode67.py). Bit-exact everywhere."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import decoder as D
+from libcimbar_amd import framegen, geometry
+from oracle import pyref
+from oracle.pyref import P
+from tests import frames as F
+
+pytestmark = pytest.mark.gpu
+MODE = 67
+GEO = geometry.for_mode(MODE)
+
+
+@pytest.fixture(scope="module")
+def dec67():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return D.HipDecoder(0, MODE)
+
+
+@pytest.fixture(scope="module")
+def synth67():
+    return framegen.FrameSynth("cpu", MODE)
+
+
+def oracle_batch(frames, pre=0, cc=2):
+    ccm = pyref.CoCcm()
+    outs = []
+    for fr in frames:
+        r, chunks, mask, ccm = pyref.oracle_decode(fr, pre, cc, ccm, mode=MODE)
+        sym, col, pos = pyref.oracle_stage(mode=MODE)
+        outs.append(dict(r=r, chunks=chunks.copy(), mask=mask, sym=sym, col=col, pos=pos, ccm=np.array(list(ccm.m), np.float32), active=ccm.active))
+    return outs
+
+
+def check(dec, frames, pre=0, cc=2, names=None):
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    dec.reset_ccm()
+    total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre, color_correction=cc)
+    want = oracle_batch(frames, pre, cc)
+    sym, col, drift, ccm = dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_COLORS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_CCM, n)
+    xy = GEO.cell_positions()
+    for k in range(n):
+        tag = names[k] if names else str(k)
+        w = want[k]
+        assert (sym[k] == w["sym"]).all(), f"{tag}: symbols differ in {(sym[k] != w['sym']).sum()} cells"
+        assert (xy + drift[k].astype(np.int32) == w["pos"]).all(), f"{tag}: colour positions differ"
+        assert ccm[k, :9].tobytes() == w["ccm"].tobytes() or not w["active"], f"{tag}: CCM differs"
+        assert bool(ccm[k, 9]) == bool(w["active"]), f"{tag}: CCM active flag"
+        assert (col[k] == w["col"]).all(), f"{tag}: colours differ in {(col[k] != w['col']).sum()} cells"
+        assert masks[k] == w["mask"], f"{tag}: mask {masks[k]:#x} vs {w['mask']:#x}"
+        assert (chunks[k] == w["chunks"]).all(), f"{tag}: chunk bytes differ"
+    assert total == sum(w["r"] for w in want)
+    return chunks, masks, want
+
+
+def test_geometry_reported_by_the_library(dec67):
+    g = dec67.geo
+    assert (g.MODE, g.IMG_W, g.IMG_H, g.NCELLS, g.CHUNK, g.BLOCKS, g.RS_BLOCK, g.RS_PARITY) == (67, 1024, 720, 8592, 429, 36, 179, 36)
+    o = (ctypes.c_int32 * 10)()
+    pyref.oracle_lib(MODE).co_geometry(o)
+    assert list(o) == [67, g.IMG_W, g.IMG_H, g.NCELLS, g.CHUNK, g.RS_BLOCK, g.RS_PARITY, g.DIM_X, g.DIM_Y, g.OFFSET]
+
+
+def test_clean_batch_bit_exact(dec67, synth67):
+    payload, frames = F.clean_frames(synth67, 6, seed=1234)
+    chunks, masks, _ = check(dec67, list(frames))
+    assert (masks == 0xFFF).all()
+    assert (chunks.reshape(6, -1) == payload).all()
+    assert not dec67.tap(D.TAP_FLOOD, 6).any(), "clean frames must take the parallel path"
+
+
+def test_bitplane_matches_oracle(dec67, synth67):
+    _, frames = F.clean_frames(synth67, 2, seed=9)
+    frames = [frames[0], F.add_noise(frames[1], 60, 5)]
+    O = pyref.oracle_lib(MODE)
+    for pre in (0, 1):
+        dec67.decode_batch(np.stack(frames), should_preprocess=pre)
+        got = dec67.tap(D.TAP_BITPLANE, 2)
+        for k in range(2):
+            want = np.zeros(GEO.IMG_W * GEO.IMG_H // 8, np.uint8)
+            O.co_threshold_bitplane(P(np.ascontiguousarray(frames[k])), GEO.IMG_W, GEO.IMG_H, pre, P(want))
+            assert (got[k] == want).all(), f"pre={pre} frame {k}: {(got[k] != want).sum()} bitplane bytes differ"
+
+
+@pytest.mark.parametrize("pre,cc", [(0, 2), (1, 2), (0, 1), (1, 0)])
+def test_distorted_frames_match_oracle(dec67, synth67, pre, cc):
+    items = F.distorted_set(synth67)
+    check(dec67, [fr for _, fr in items], pre=pre, cc=cc, names=[nm for nm, _ in items])
+
+
+def test_tile_substitution_errors_are_corrected(dec67, synth67):
+    payload, frames = F.tile_error_frames(synth67, 4, seed=4321, n_errors=99)
+    chunks, masks, _ = check(dec67, list(frames))
+    assert (masks == 0xFFF).all() and (chunks.reshape(4, -1) == payload).all()
+    assert dec67.tap(D.TAP_RS_OK, 4).all()
+
+
+def test_flood_paths(dec67, synth67):
+    """shifted frames certify on the batch-parallel flood, noisy shifted frames fall back to the exact replay: both equal the oracle"""
+    _, frames = F.clean_frames(synth67, 4, seed=31)
+    fr = [F.shift(frames[0], 2, 1), F.shift(frames[1], -3, 2), F.add_noise(F.shift(frames[2], 1, -2), 50, 7), F.rescale(frames[3], 6)]
+    check(dec67, fr)
+    assert dec67.tap(D.TAP_FLOOD, 4).all()
+    path = dec67.tap(D.TAP_FLOOD_PATH, 4)
+    assert set(path.tolist()) <= {1, 2} and (path[:2] == 2).all(), path
+
+
+def test_decode_plain_matches_oracle(dec67, synth67):
+    payload, frames = F.clean_frames(synth67, 3, seed=77)
+    frames = [frames[0], F.add_noise(frames[1], 120, 2), F.blank_region(frames[2], 200, 330, 0, 1024)]
+    dec67.reset_ccm()
+    r, data, ok = dec67.decode_plain_batch(np.stack(frames))
+    ccm = pyref.CoCcm()
+    tot = 0
+    for k, fr in enumerate(frames):
+        wr, wdata, wok, ccm = pyref.oracle_decode_plain(fr, 0, 2, ccm, mode=MODE)
+        tot += wr
+        assert (ok[k] == wok).all() and (data[k] == wdata).all(), k
+    assert r == tot and (data[0] == payload[0]).all()
+
+
+def test_encode_matches_reference_encoder(dec67, synth67):
+    """E1 + E2 in mode 67 against FrameSynth(67), which tests/test_mode67.py pins byte-for-byte to the reference's Encoder::encode_next"""
+    payload = framegen.synth_payload(5, seed=8, mode=MODE)
+    want = synth67.frames_from_payload(payload).numpy()
+    got = dec67.encode_batch(payload.numpy())
+    assert got.shape == (5, 720, 1024, 3) and (got == want).all()
+
+
+def test_pipelined_batches(dec67, synth67):
+    payload, frames = F.clean_frames(synth67, 8, seed=5)
+    dev = torch.device("cuda:0")
+    d_in = [torch.from_numpy(frames[4 * k:4 * k + 4].copy()).to(dev) for k in range(2)]
+    d_ch = [torch.zeros((4, GEO.FRAME_BYTES), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_mk = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(2)]
+    st = torch.cuda.current_stream().cuda_stream
+    dec67.reset_ccm()
+    for k in range(2):
+        dec67.decode_batch_pipelined(d_in[k].data_ptr(), 4, d_ch[k].data_ptr(), d_mk[k].data_ptr(), stream=st)
+    dec67.pipeline_wait(stream=st)
+    torch.cuda.synchronize()
+    got = torch.cat(d_ch).cpu().numpy()
+    assert (got == payload).all() and all((m.cpu().numpy() == 0xFFF).all() for m in d_mk)
+
+
+def test_wrong_frame_size_is_rejected_and_both_modes_coexist(dec67, synth67, hip_decoder, synth):
+    sq = np.zeros((1024, 1024, 3), np.uint8)
+    with pytest.raises(D.CimbarHipError, match="EDIM"):
+        dec67.decode_frame(sq)
+    with pytest.raises(D.CimbarHipError, match="EDIM"):
+        hip_decoder.decode_frame(np.zeros((720, 1024, 3), np.uint8))
+    pb, fb = F.clean_frames(synth, 2, seed=3)
+    pm, fm = F.clean_frames(synth67, 2, seed=3)
+    for k in range(2):          # interleaved calls on the two contexts: each keeps its own tables, constants and CCM
+        _, cb, mb = hip_decoder.decode_frame(fb[k])
+        _, cm, mm = dec67.decode_frame(fm[k])
+        assert mb == 0xFFF and mm == 0xFFF and (cb.reshape(-1) == pb[k]).all() and (cm.reshape(-1) == pm[k]).all()
+    with pytest.raises(D.CimbarHipError):
+        D.HipDecoder(0, 66)          # Conf8x8_micro is not built
+
+
+def test_camera_captures_scan_extract_decode(dec67, synth67):
+    """cimbard_scan_extract_decode in mode 67: 1080p captures of 1024x720 frames -> anchors -> 1024x720 deskew -> decode, against the oracle's
+    co_extract + co_decode_fountain built for the same mode"""
+    quads = [((300, 150), (1600, 170), (290, 930), (1620, 915)), ((250, 100), (1700, 100), (250, 1000), (1700, 1000)), ((420, 200), (1500, 230), (400, 900), (1480, 880))]
+    payload, frames = F.clean_frames(synth67, len(quads), seed=44)
+    cams = np.ascontiguousarray(np.stack([F.camera_frame(frames[k], quad=q, background=bg, blur=bl) for k, (q, bg, bl) in enumerate(zip(quads, (0, 40, 255), (0.0, 0.6, 0.0)))]))
+    O = pyref.oracle_lib(MODE)
+    n, h, w = cams.shape[:3]
+    status, corners, out = dec67.extract_batch(cams)
+    ccm = pyref.CoCcm()
+    want_chunks, want_masks, want_status = [], [], []
+    for k in range(n):
+        fr = np.zeros(GEO.FRAME_SHAPE, np.uint8)
+        c8 = (ctypes.c_float * 8)()
+        st = O.co_extract(P(cams[k]), w, h, P(fr), c8)
+        want_status.append(st)
+        assert status[k] == st and st != 0, (k, status[k], st)
+        assert list(corners[k]) == list(c8)
+        assert (out[k] == fr).all(), f"capture {k}: {(out[k] != fr).sum()} deskewed bytes differ"
+        r, ch, m, ccm = pyref.oracle_decode(fr, 1 if st == 2 else 0, 2, ccm, mode=MODE)
+        want_chunks.append(ch.copy()); want_masks.append(m)
+    dec67.reset_ccm()
+    total, chunks, masks, st2 = dec67.scan_extract_decode_batch(cams)
+    assert list(st2) == want_status and list(masks) == want_masks
+    for k in range(n):
+        assert (chunks[k] == want_chunks[k]).all(), k
+    assert (masks == 0xFFF).sum() >= 2          # the captures do decode
+
+
+def test_full_batch_round_trip(dec67):
+    """1024 frames rendered and decoded in HBM: every payload byte back, every chunk delivered (size-independent property at bench size)"""
+    dev = torch.device("cuda:0")
+    n = 1024
+    payload = framegen.synth_payload(n, seed=99, mode=MODE).to(dev)
+    frames = torch.empty((n, *GEO.FRAME_SHAPE), dtype=torch.uint8, device=dev)
+    dec67.encode_batch_device(payload.data_ptr(), n, frames.data_ptr())
+    chunks = torch.zeros((n, GEO.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    masks = torch.zeros(n, dtype=torch.int32, device=dev)
+    dec67.reset_ccm()
+    dec67.decode_batch_device(frames.data_ptr(), n, chunks.data_ptr(), masks.data_ptr())
+    torch.cuda.synchronize()
+    assert bool((masks == 0xFFF).all()) and bool((chunks == payload).all())
+
+
+def test_golden_vectors_of_the_reference_build(dec67, synth67):
+    """tests/golden/mode67.json: what the reference build returned for these frames in mode 67, decoded as ONE batch on the GPU (the CCM
+    carried frame to frame inside the batch like the reference's decode thread carries it)"""
+    import hashlib
+    import json
+    import os
+    from oracle.make_golden_mode67 import cases
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mode67.json")))
+    items = cases(synth67)
+    for pre in (0, 1):          # a batch has one should_preprocess flag: the two halves of the list are two batches, the second continuing the first's CCM
+        rows = [(it, row) for it, row in zip(items, fix["frames"]) if row["preprocess"] == pre]
+        frames = np.ascontiguousarray(np.stack([it[2] for it, _ in rows]))
+        if pre == 0:
+            dec67.reset_ccm()
+        total, chunks, masks = dec67.decode_batch(frames, should_preprocess=pre, color_correction=2)
+        for k, (it, row) in enumerate(rows):
+            assert hashlib.sha256(frames[k].tobytes()).hexdigest() == row["frame_sha256"]
+            assert int(masks[k]) == row["mask"], row["name"]
+            assert hashlib.sha256(chunks[k].tobytes()).hexdigest() == row["chunks_sha256"], row["name"]
+        assert total == sum(row["good_bytes"] for _, row in rows)
