@@ -19,7 +19,7 @@ extern "C" {
 enum {
 	CIMBAR_INGEST_EFORMAT = -20,   /* not a PNG this decoder handles (interlaced, unknown colour type, corrupt stream) */
 	CIMBAR_INGEST_EIO = -21,       /* a file could not be read */
-	CIMBAR_INGEST_ESIZE = -22      /* an image is not 1024x1024 (frames must be deskewed already: the --no-deskew path, cimbar.cpp:136) */
+	CIMBAR_INGEST_ESIZE = -22      /* an image is not image_size_x x image_size_y of the context's mode (frames must be deskewed already: the --no-deskew path, cimbar.cpp:136) */
 };
 
 /* One PNG in memory -> tightly packed RGB8 (what cv::imread + BGR2RGB hands the decoder: alpha dropped, gray replicated).
@@ -28,7 +28,8 @@ int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_c
 
 typedef struct cimbar_ingest cimbar_ingest;
 
-/* called once per batch, in frame order, from the thread that called cimbar_ingest_run_*: chunks = n * 7500 bytes, masks = n words (host
+/* called once per batch, in frame order, from the thread that called cimbar_ingest_run_*: chunks = n * 7500 bytes (mode B; in general n *
+ * geometry[4] * geometry[5] of cimbar_hip_geometry), masks = n words (host
  * memory, valid during the call); first_frame = index of the batch's first frame in the input list. Return non-zero to stop early
  * (e.g. the fountain sink is complete). */
 typedef int (*cimbar_ingest_sink_fn)(void* user, const uint8_t* chunks, const uint32_t* masks, int first_frame, int n);
@@ -39,8 +40,8 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
 void cimbar_ingest_destroy(cimbar_ingest* ing);
 const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
 
-/* ./cimbar --no-deskew img1.png img2.png ... (cimbar.cpp:124-162, fountain mode): every file is a deskewed 1024x1024 frame. Files that
- * cannot be read or are not 1024x1024 PNGs are skipped like the reference skips frames it cannot decode (their slots deliver nothing).
+/* ./cimbar --no-deskew img1.png img2.png ... (cimbar.cpp:124-162, fountain mode): every file is a deskewed frame of the context's mode (1024x1024 in mode B,
+ * 1024x720 in mode 67). Files that cannot be read or are not PNGs of that size are skipped like the reference skips frames it cannot decode (their slots deliver nothing).
  * Returns the total good bytes (sum of what Decoder::decode_fountain would have returned per frame) or a negative code. */
 int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, int nfiles, int should_preprocess, int color_correction,
                                 cimbar_ingest_sink_fn sink, void* user);

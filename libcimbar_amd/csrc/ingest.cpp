@@ -24,7 +24,6 @@
 
 namespace {
 
-constexpr size_t FRAME = (size_t)CIMBAR_HIP_FRAME_DIM * CIMBAR_HIP_FRAME_DIM * 3;
 
 // ---------------------------------------------------------------------------------------------------------------- PNG
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -147,6 +146,9 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // ---------------------------------------------------------------------------------------------------------------- pipeline
 struct cimbar_ingest {
+	unsigned fw = 0, fh = 0;          // image_size_x / image_size_y of the context's mode (cimbar_hip_geometry)
+	size_t frame = 0, frame_bytes = 0; // RGB8 bytes per frame; chunk bytes per frame (chunks per frame * chunk size)
+	unsigned chunk = 0;
 	cimbar_hip_ctx* ctx = nullptr;
 	int device = 0, threads = 1, B = 64, R = 3;
 	std::string err;
@@ -200,7 +202,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			}
 			if (stop.load()) break;
 			const double t0 = now_s();
-			const bool ok = fill(i, ing->slots[s].h_in + (size_t)(i - k * B) * FRAME);
+			const bool ok = fill(i, ing->slots[s].h_in + (size_t)(i - k * B) * ing->frame);
 			ing->slots[s].valid[(size_t)(i - k * B)] = ok ? 1 : 0;
 			mine += now_s() - t0;
 			{
@@ -228,8 +230,8 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 		wait_s += now_s() - t0;
 		if (e != hipSuccess) { ing->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return CIMBAR_HIP_EHIP; }
 		for (int j = 0; j < m; ++j) {
-			if (!sl.valid[(size_t)j]) { sl.h_masks[j] = 0; std::memset(sl.h_chunks + (size_t)j * CIMBAR_HIP_FRAME_BYTES, 0, CIMBAR_HIP_FRAME_BYTES); }
-			total += (int64_t)CIMBAR_HIP_CHUNK_SIZE * __builtin_popcount(sl.h_masks[j] & 0xFFFu);
+			if (!sl.valid[(size_t)j]) { sl.h_masks[j] = 0; std::memset(sl.h_chunks + (size_t)j * ing->frame_bytes, 0, ing->frame_bytes); }
+			total += (int64_t)ing->chunk * __builtin_popcount(sl.h_masks[j] & 0xFFFu);
 		}
 		const int stop_now = sink ? sink(user, sl.h_chunks, sl.h_masks, k * B, m) : 0;
 		{
@@ -249,13 +251,13 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			cv.wait(lk, [&] { return filled[(size_t)k] == m; });
 			(void)t0;
 		}
-		hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, (size_t)m * FRAME, hipMemcpyHostToDevice, ing->copy_stream);
+		hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
 		if (e != hipSuccess) { ing->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
 		// "the frames are whatever hip_stream has produced up to here": the library's own stream waits for the copy
 		int r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, ing->copy_stream);
 		if (r == 0) r = cimbar_hip_pipeline_wait(ing->ctx, ing->out_stream, 0);
 		if (r != 0) { ing->err = std::string("decode: ") + cimbar_hip_last_error(ing->ctx); rc = r; break; }
-		(void)hipMemcpyAsync(sl.h_chunks, sl.d_chunks, (size_t)m * CIMBAR_HIP_FRAME_BYTES, hipMemcpyDeviceToHost, ing->out_stream);
+		(void)hipMemcpyAsync(sl.h_chunks, sl.d_chunks, (size_t)m * ing->frame_bytes, hipMemcpyDeviceToHost, ing->out_stream);
 		(void)hipMemcpyAsync(sl.h_masks, sl.d_masks, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, ing->out_stream);
 		(void)hipEventRecord(sl.done, ing->out_stream);
 		// keep R - 1 batches in flight behind the one just issued
@@ -302,6 +304,12 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
 	cimbar_ingest* ing = new cimbar_ingest();
 	ing->ctx = ctx;
 	ing->device = cimbar_hip_device(ctx);
+	int32_t geo[CIMBAR_HIP_GEOMETRY_WORDS];
+	if (cimbar_hip_geometry(ctx, geo) != CIMBAR_HIP_GEOMETRY_WORDS) { delete ing; return CIMBAR_HIP_EINVAL; }
+	ing->fw = (unsigned)geo[1]; ing->fh = (unsigned)geo[2];
+	ing->frame = (size_t)geo[1] * geo[2] * 3;
+	ing->chunk = (unsigned)geo[5];
+	ing->frame_bytes = (size_t)geo[4] * geo[5];
 	int hw = (int)std::thread::hardware_concurrency();
 	if (hw <= 0) hw = 8;
 	ing->threads = threads > 0 ? threads : (hw > 64 ? 64 : hw);
@@ -317,10 +325,10 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
 	ing->slots.resize((size_t)ing->R);
 	for (auto& s : ing->slots) {
 		const size_t nb = (size_t)ing->B;
-		if (hipHostMalloc((void**)&s.h_in, nb * FRAME, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
-		if (hipMalloc((void**)&s.d_in, nb * FRAME) != hipSuccess) return fail("device input");
-		if (hipHostMalloc((void**)&s.h_chunks, nb * CIMBAR_HIP_FRAME_BYTES, hipHostMallocDefault) != hipSuccess) return fail("pinned chunks");
-		if (hipMalloc((void**)&s.d_chunks, nb * CIMBAR_HIP_FRAME_BYTES) != hipSuccess) return fail("device chunks");
+		if (hipHostMalloc((void**)&s.h_in, nb * ing->frame, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
+		if (hipMalloc((void**)&s.d_in, nb * ing->frame) != hipSuccess) return fail("device input");
+		if (hipHostMalloc((void**)&s.h_chunks, nb * ing->frame_bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned chunks");
+		if (hipMalloc((void**)&s.d_chunks, nb * ing->frame_bytes) != hipSuccess) return fail("device chunks");
 		if (hipHostMalloc((void**)&s.h_masks, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail("pinned masks");
 		if (hipMalloc((void**)&s.d_masks, nb * sizeof(uint32_t)) != hipSuccess) return fail("device masks");
 		if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return fail("event");
@@ -359,8 +367,8 @@ int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, in
 		if (!read_file(paths[i], file)) return false;
 		unsigned w = 0, h = 0;
 		if (png_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0) return false;
-		if (w != (unsigned)CIMBAR_HIP_FRAME_DIM || h != (unsigned)CIMBAR_HIP_FRAME_DIM) return false;   // (larger, padded frames: not supported on this path)
-		return png_decode(file.data(), file.size(), dst, FRAME, &w, &h, idat, raw) == 0;
+		if (w != ing->fw || h != ing->fh) return false;   // (larger, padded frames: not supported on this path)
+		return png_decode(file.data(), file.size(), dst, ing->frame, &w, &h, idat, raw) == 0;
 	};
 	return run_pipeline(ing, nfiles, should_preprocess, color_correction, sink, user, fill);
 }
@@ -369,7 +377,7 @@ int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, 
                               cimbar_ingest_sink_fn sink, void* user)
 {
 	if (!ing || !frames || n < 0) return CIMBAR_HIP_EINVAL;
-	auto fill = [&](int i, uint8_t* dst) -> bool { std::memcpy(dst, frames + (size_t)i * FRAME, FRAME); return true; };
+	auto fill = [&](int i, uint8_t* dst) -> bool { std::memcpy(dst, frames + (size_t)i * ing->frame, ing->frame); return true; };
 	return run_pipeline(ing, n, should_preprocess, color_correction, sink, user, fill);
 }
 

@@ -46,12 +46,14 @@ struct PositionData   // src/lib/cimb_translator/PositionData.h
 class Decoder
 {
 public:
-	// Decoder(use_ecc, interleave) as in Decoder.h:40-45. Only the reference's defaults (ECC on, interleave on, mode 68) exist on
-	// the GPU path; anything else leaves the object !good() and every decode returns 0, like a reference decode that found nothing.
+	// Decoder(use_ecc, interleave) as in Decoder.h:40-45. Only the reference's defaults (ECC on, interleave on) exist on the GPU path, in the
+	// modes cimbar_hip_create builds (68 "B", 67 "Bm" -- what cimbard_configure_decode / Config::update(mode_val) selects in the reference);
+	// anything else leaves the object !good() and every decode returns 0, like a reference decode that found nothing.
 	explicit Decoder(bool use_ecc = true, bool interleave = true, int device = 0, int mode_val = 68)
 	{
 		if (use_ecc && interleave) _rc = cimbar_hip_create(device, mode_val, &_ctx);
 		else _rc = CIMBAR_HIP_EINVAL;
+		if (_ctx && cimbar_hip_geometry(_ctx, _geo) != CIMBAR_HIP_GEOMETRY_WORDS) { cimbar_hip_destroy(_ctx); _ctx = nullptr; _rc = CIMBAR_HIP_EHIP; }
 	}
 	~Decoder() { if (_ctx) cimbar_hip_destroy(_ctx); }
 	Decoder(const Decoder&) = delete;
@@ -61,6 +63,18 @@ public:
 	int error_code() const { return _rc; }
 	const char* last_error() const { return cimbar_hip_last_error(_ctx); }
 	cimbar_hip_ctx* context() { return _ctx; }
+
+	// the Config:: getters of the context's mode (Config.h:52-165). The CIMBAR_HIP_* macros of cimbar_hip.h are mode B's values, the largest
+	// of the built modes, so buffers sized with them hold either.
+	unsigned image_size_x() const { return (unsigned)_geo[1]; }
+	unsigned image_size_y() const { return (unsigned)_geo[2]; }
+	unsigned total_cells() const { return (unsigned)_geo[3]; }
+	unsigned fountain_chunks_per_frame() const { return (unsigned)_geo[4]; }
+	unsigned fountain_chunk_size() const { return (unsigned)_geo[5]; }
+	unsigned frame_bytes() const { return (unsigned)(_geo[4] * _geo[5]); }
+	unsigned cells_per_col_x() const { return (unsigned)_geo[9]; }
+	unsigned cells_per_col_y() const { return (unsigned)_geo[10]; }
+	unsigned cell_offset() const { return (unsigned)_geo[11]; }
 
 	// Decoder::decode_fountain (Decoder.h:171-189): good chunks reach ostream.write(buf, 625) in chunk order, exactly what
 	// aligned_stream would have delivered; returns the cumulative good bytes. A sink whose chunk_size() is not 625 receives
@@ -76,9 +90,10 @@ public:
 		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
 		_rc = res < 0 ? res : 0;
 		if (res <= 0) return 0;   // CimbReader::_good == false / nothing decoded
-		if (ostream.chunk_size() == (unsigned)CIMBAR_HIP_CHUNK_SIZE)
-			for (int j = 0; j < CIMBAR_HIP_CHUNKS_PER_FRAME; ++j)
-				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * CIMBAR_HIP_CHUNK_SIZE, CIMBAR_HIP_CHUNK_SIZE);
+		const unsigned cs = fountain_chunk_size();
+		if (ostream.chunk_size() == cs)
+			for (unsigned j = 0; j < fountain_chunks_per_frame(); ++j)
+				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * cs, cs);
 		return (unsigned)res;
 	}
 
@@ -89,13 +104,13 @@ public:
 	unsigned decode(const MAT& img, STREAM& ostream, bool should_preprocess = false, int color_correction = 2)
 	{
 		if (!_ctx) return 0;
-		if ((unsigned)img.cols != (unsigned)CIMBAR_HIP_FRAME_DIM || (unsigned)img.rows != (unsigned)CIMBAR_HIP_FRAME_DIM) { _rc = CIMBAR_HIP_EDIM; return 0; }
+		if ((unsigned)img.cols != image_size_x() || (unsigned)img.rows != image_size_y()) { _rc = CIMBAR_HIP_EDIM; return 0; }
 		std::vector<unsigned char> packed;
 		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
-		const size_t step = image_step(img), dense = (size_t)CIMBAR_HIP_FRAME_DIM * 3;
+		const size_t step = image_step(img), dense = (size_t)image_size_x() * 3;
 		if (step != dense) {
-			packed.resize(dense * CIMBAR_HIP_FRAME_DIM);
-			for (int y = 0; y < CIMBAR_HIP_FRAME_DIM; ++y)
+			packed.resize(dense * image_size_y());
+			for (int y = 0; y < (int)image_size_y(); ++y)
 				for (size_t k = 0; k < dense; ++k) packed[(size_t)y * dense + k] = src[(size_t)y * step + k];
 			src = packed.data();
 		}
@@ -104,29 +119,28 @@ public:
 		                                            CIMBAR_HIP_MEM_HOST, nullptr);
 		_rc = res < 0 ? (int)res : 0;
 		if (res <= 0) return 0;
-		ostream.write(reinterpret_cast<const char*>(bytes), CIMBAR_HIP_FRAME_BYTES);
+		ostream.write(reinterpret_cast<const char*>(bytes), frame_bytes());
 		return (unsigned)ostream.tellp();
 	}
 
-	// n densely packed 1024x1024 RGB8 frames in host memory, decoded on the GPU in one batch; chunks go to the sink in frame
+	// n densely packed image_size_x x image_size_y RGB8 frames in host memory, decoded on the GPU in one batch; chunks go to the sink in frame
 	// order then chunk order (what a single-threaded reference loop over the frames would have produced). Returns total good bytes.
 	template <typename FOUNTAINSTREAM>
 	unsigned long long decode_fountain_batch(const unsigned char* frames, int n, FOUNTAINSTREAM& ostream, bool should_preprocess = false,
 	                                         int color_correction = 2)
 	{
 		if (!_ctx || n <= 0) return 0;
-		_chunks.resize((size_t)n * CIMBAR_HIP_FRAME_BYTES);
+		const unsigned cs = fountain_chunk_size(), per = fountain_chunks_per_frame();
+		_chunks.resize((size_t)n * cs * per);
 		_masks.resize((size_t)n);
 		int64_t res = cimbar_hip_decode_batch(_ctx, frames, n, CIMBAR_HIP_MEM_HOST, should_preprocess ? 1 : 0, color_correction,
 		                                      _chunks.data(), _masks.data(), CIMBAR_HIP_MEM_HOST, nullptr);
 		_rc = res < 0 ? (int)res : 0;
 		if (res <= 0) return 0;
-		if (ostream.chunk_size() == (unsigned)CIMBAR_HIP_CHUNK_SIZE)
+		if (ostream.chunk_size() == cs)
 			for (int f = 0; f < n; ++f)
-				for (int j = 0; j < CIMBAR_HIP_CHUNKS_PER_FRAME; ++j)
-					if (_masks[f] & (1u << j))
-						ostream.write(reinterpret_cast<const char*>(_chunks.data()) + ((size_t)f * CIMBAR_HIP_CHUNKS_PER_FRAME + j) * CIMBAR_HIP_CHUNK_SIZE,
-						              CIMBAR_HIP_CHUNK_SIZE);
+				for (unsigned j = 0; j < per; ++j)
+					if (_masks[f] & (1u << j)) ostream.write(reinterpret_cast<const char*>(_chunks.data()) + ((size_t)f * per + j) * cs, cs);
 		return (unsigned long long)res;
 	}
 
@@ -142,6 +156,7 @@ protected:
 
 	cimbar_hip_ctx* _ctx = nullptr;
 	int _rc = 0;
+	int32_t _geo[CIMBAR_HIP_GEOMETRY_WORDS] = {};
 	std::vector<unsigned char> _chunks;
 	std::vector<uint32_t> _masks;
 };
@@ -151,7 +166,7 @@ protected:
 // Decoder::do_decode places every result by pos.i, Decoder.h:84-97, so the order is not observable there) and returns the
 // 4 symbol bits plus the drifted position the colour pass used; read_color() returns the 2 colour bits of that cell.
 // CimbDecoder as CimbReader's constructor wants it (cimb_translator/CimbDecoder.h: CimbDecoder(symbol_bits, color_bits, dark, ahashThreshold)):
-// the tile hashes and the colour-correction state live in the device context, so this only names one. Mode B only: 4 symbol bits, 2 colour bits.
+// the tile hashes and the colour-correction state live in the device context, so this only names one. 8x8 modes only: 4 symbol bits, 2 colour bits.
 class CimbDecoder
 {
 public:
@@ -189,9 +204,11 @@ public:
 		_good = decoder.good() && cimbar_hip_decode_frame(decoder.context(), reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols,
 		                                                  (unsigned)img.rows, step, needs_sharpen ? 1 : 0, color_correction, chunks, &mask) >= 0;
 		if (!_good) return;
-		_symbols.resize(CIMBAR_HIP_CELLS);
-		_colors.resize(CIMBAR_HIP_CELLS);
-		_drift.resize((size_t)CIMBAR_HIP_CELLS * 2);
+		_cells = decoder.total_cells();
+		_dim_x = (int)decoder.cells_per_col_x(); _dim_y = (int)decoder.cells_per_col_y(); _offset = (int)decoder.cell_offset();
+		_symbols.resize(_cells);
+		_colors.resize(_cells);
+		_drift.resize((size_t)_cells * 2);
 		_good = cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_SYMBOLS, _symbols.data(), _symbols.size()) >= 0 &&
 		        cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_COLORS, _colors.data(), _colors.size()) >= 0 &&
 		        cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_DRIFT, _drift.data(), _drift.size()) >= 0;
@@ -209,20 +226,22 @@ public:
 		return _symbols[i];
 	}
 	unsigned read_color(const PositionData& pos) const { return pos.i < _colors.size() ? _colors[pos.i] : 0; }
-	bool done() const { return !_good || _next >= (unsigned)CIMBAR_HIP_CELLS; }
-	unsigned num_reads() const { return CIMBAR_HIP_CELLS; }
+	bool done() const { return !_good || _next >= _cells; }
+	unsigned num_reads() const { return _cells; }
 
-	// CellPositions::compute_linear for Conf8x8 (CellPositions.cpp:5-51)
-	static void cell_xy(unsigned i, int& x, int& y)
+	// CellPositions::compute_linear (CellPositions.cpp:5-51) for the decoder's grid: cell pitch 9, 6 marker cells per corner
+	void cell_xy(unsigned i, int& x, int& y) const
 	{
-		if (i < 600) { x = 62 + (int)(i % 100) * 9; y = 8 + (int)(i / 100) * 9; }
-		else if (i < 11800) { unsigned j = i - 600; x = 8 + (int)(j % 112) * 9; y = 62 + (int)(j / 112) * 9; }
-		else { unsigned j = i - 11800; x = 62 + (int)(j % 100) * 9; y = 962 + (int)(j / 100) * 9; }
+		const int top_w = _dim_x - 12, top = top_w * 6, mid = _dim_x * (_dim_y - 12);
+		if ((int)i < top) { x = _offset + 54 + (int)(i % top_w) * 9; y = _offset + (int)(i / top_w) * 9; }
+		else if ((int)i < top + mid) { unsigned j = i - top; x = _offset + (int)(j % _dim_x) * 9; y = _offset + 54 + (int)(j / _dim_x) * 9; }
+		else { unsigned j = i - top - mid; x = _offset + 54 + (int)(j % top_w) * 9; y = _offset + (_dim_y - 6) * 9 + (int)(j / top_w) * 9; }
 	}
 
 protected:
 	bool _good = false;
-	unsigned _next = 0;
+	unsigned _next = 0, _cells = 0;
+	int _dim_x = 112, _dim_y = 112, _offset = 8;
 	std::vector<unsigned char> _symbols, _colors;
 	std::vector<signed char> _drift;
 };
@@ -265,7 +284,7 @@ public:
 		for (int i = 0; i < 4; ++i) { c8[2 * i] = (float)pts[i].x; c8[2 * i + 1] = (float)pts[i].y; }
 		std::vector<unsigned char> packed;
 		const unsigned char* src = dense_rgb(img, packed);
-		out = image(CIMBAR_HIP_FRAME_DIM, CIMBAR_HIP_FRAME_DIM, 3);
+		out = image((int)_dec.image_size_x(), (int)_dec.image_size_y(), 3);
 		if (cimbar_hip_deskew_batch(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, c8, out.data,
 		                            CIMBAR_HIP_MEM_HOST, nullptr) != 0)
 			out = image();
@@ -315,7 +334,7 @@ public:
 	static constexpr int SUCCESS = 1;
 	static constexpr int NEEDS_SHARPEN = 2;
 
-	// Extractor(padding, image_size, anchor_size): only the defaults the reference's callers use (0, Config's 1024x1024, Config's 30)
+	// Extractor(padding, image_size, anchor_size): only the defaults the reference's callers use (0, Config's image_size_x x image_size_y, Config's 30)
 	explicit Extractor(Decoder& decoder) : _dec(decoder) {}
 
 	template <typename MAT>
@@ -324,16 +343,17 @@ public:
 		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return FAILURE;
 		std::vector<unsigned char> packed;
 		const unsigned char* src = Deskewer::dense(img, packed);
-		std::vector<unsigned char> frame((size_t)CIMBAR_HIP_FRAME_DIM * CIMBAR_HIP_FRAME_DIM * 3);
+		const int fw = (int)_dec.image_size_x(), fh = (int)_dec.image_size_y();
+		std::vector<unsigned char> frame((size_t)fw * fh * 3);
 		int status = 0;
 		if (cimbar_hip_extract_batch(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, frame.data(), &status, _corners,
 		                             CIMBAR_HIP_MEM_HOST, nullptr) != 0)
 			return FAILURE;
 		if (status <= 0) return FAILURE;
-		out.create(CIMBAR_HIP_FRAME_DIM, CIMBAR_HIP_FRAME_DIM, img.type());
-		for (int y = 0; y < CIMBAR_HIP_FRAME_DIM; ++y)
-			for (size_t k = 0; k < (size_t)CIMBAR_HIP_FRAME_DIM * 3; ++k)
-				out.data[(size_t)y * out.step + k] = frame[(size_t)y * CIMBAR_HIP_FRAME_DIM * 3 + k];
+		out.create(fh, fw, img.type());
+		for (int y = 0; y < fh; ++y)
+			for (size_t k = 0; k < (size_t)fw * 3; ++k)
+				out.data[(size_t)y * out.step + k] = frame[(size_t)y * fw * 3 + k];
 		return status;
 	}
 

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from . import decoder, modeb
+from . import decoder
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_ingest.so")
@@ -72,11 +72,11 @@ class Ingest:
             self._h = ctypes.c_void_p()
 
     def _collect(self, n):
-        chunks = np.zeros((n, modeb.FRAME_BYTES), np.uint8)
+        chunks = np.zeros((n, self._dec.geo.FRAME_BYTES), np.uint8)
         masks = np.zeros(n, np.uint32)
 
         def cb(user, c, m, first, cnt):
-            chunks[first:first + cnt] = np.ctypeslib.as_array(c, shape=(cnt, modeb.FRAME_BYTES))
+            chunks[first:first + cnt] = np.ctypeslib.as_array(c, shape=(cnt, self._dec.geo.FRAME_BYTES))
             masks[first:first + cnt] = np.ctypeslib.as_array(m, shape=(cnt,))
             return 0
         return chunks, masks, SINK_FN(cb)

@@ -119,11 +119,41 @@ int main(int argc, char** argv)
 		unsigned col = reader.read_color(pos);
 		CHECK(sym == cells[pos.i] && col == cells[12400 + pos.i]);
 		int x, y;
-		cimbar_amd::CimbReader::cell_xy(pos.i, x, y);
+		reader.cell_xy(pos.i, x, y);
 		CHECK(pos.x == x && pos.y == y);   // clean frame: no drift
 		++count;
 	}
 	CHECK(count == 12400);
+
+	// mode 67 ("Bm", 1024x720, 12 x 429 bytes) through the same classes: argv[5] = frames, argv[6] = payload, argv[7] = a 1080p capture of frame 0
+	if (argc >= 8) {
+		std::vector<unsigned char> f67 = slurp(argv[5]), p67 = slurp(argv[6]), cap = slurp(argv[7]);
+		cimbar_amd::Decoder mini(true, true, 0, 67);
+		CHECK(mini.good() && mini.image_size_x() == 1024 && mini.image_size_y() == 720 && mini.fountain_chunk_size() == 429 && mini.total_cells() == 8592);
+		const size_t FM = 1024ull * 720 * 3;
+		CHECK(f67.size() == FM * n && p67.size() == 5148ull * n && cap.size() == 1920ull * 1080 * 3);
+		collecting_sink s67(429), wrong(625);
+		for (int f = 0; f < n; ++f) {
+			cimbar_amd::image_view img{f67.data() + FM * f, 1024, 720, 1024 * 3};
+			CHECK(mini.decode_fountain(img, s67) == 5148);
+			CHECK(dec.decode_fountain(img, wrong) == 0 && dec.error_code() == CIMBAR_HIP_EDIM);   // a mode-B decoder refuses the 1024x720 frame
+		}
+		CHECK(s67.bytes.size() == p67.size() && std::memcmp(s67.bytes.data(), p67.data(), p67.size()) == 0);
+		collecting_sink b67(429);
+		CHECK(mini.decode_fountain_batch(f67.data(), n, b67) == 5148ull * n && b67.bytes == s67.bytes);
+		cimbar_amd::image capture(1920, 1080, 3);          // Extractor::extract(const MAT&, MAT&): the same image type in and out
+		std::memcpy(capture.data, cap.data(), cap.size());
+		cimbar_amd::Extractor ext(mini);
+		cimbar_amd::image deskewed;
+		CHECK(ext.extract(capture, deskewed) != cimbar_amd::Extractor::FAILURE && deskewed.cols == 1024 && deskewed.rows == 720);
+		collecting_sink c67(429);
+		CHECK(mini.decode_fountain(deskewed, c67) == 5148 && std::memcmp(c67.bytes.data(), p67.data(), 5148) == 0);
+		cimbar_amd::CimbReader r67(cimbar_amd::image_view{f67.data(), 1024, 720, 1024 * 3}, mini);
+		CHECK(r67.num_reads() == 8592);
+		cimbar_amd::PositionData p0;
+		r67.read(p0);
+		CHECK(p0.x == 9 + 54 && p0.y == 9);   // CellPositions: first cell right of the top-left marker, cell_offset 9
+	}
 	std::printf("OK %d frames, %llu bytes\n", n, total);
 	return 0;
 }

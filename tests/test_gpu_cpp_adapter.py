@@ -26,7 +26,14 @@ def test_cpp_decoder_adapter(tmp_path, synth, hip_decoder):
     pyref.oracle_decode(frames[0])
     sym, col, _ = pyref.oracle_stage()
     np.concatenate([sym, col]).astype(np.uint8).tofile(tmp_path / "cells.bin")
-    res = subprocess.run([str(exe), str(tmp_path / "frames.bin"), str(tmp_path / "payload.bin"), str(tmp_path / "cells.bin"), str(n)],
+    # the same classes in mode 67 (1024x720): frames, payload, and a 1080p capture of the first frame
+    from libcimbar_amd import framegen
+    p67, f67 = F.clean_frames(framegen.FrameSynth("cpu", 67), n, seed=2025)
+    f67.tofile(tmp_path / "frames67.bin")
+    p67.tofile(tmp_path / "payload67.bin")
+    np.ascontiguousarray(F.camera_frame(f67[0], quad=((300, 150), (1600, 170), (290, 930), (1620, 915)), background=15)).tofile(tmp_path / "cap67.bin")
+    res = subprocess.run([str(exe), str(tmp_path / "frames.bin"), str(tmp_path / "payload.bin"), str(tmp_path / "cells.bin"), str(n),
+                          str(tmp_path / "frames67.bin"), str(tmp_path / "payload67.bin"), str(tmp_path / "cap67.bin")],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.startswith("OK"), res.stdout + res.stderr
 

@@ -232,3 +232,28 @@ def test_golden_vectors_of_the_reference_build(dec67, synth67):
             assert int(masks[k]) == row["mask"], row["name"]
             assert hashlib.sha256(chunks[k].tobytes()).hexdigest() == row["chunks_sha256"], row["name"]
         assert total == sum(row["good_bytes"] for _, row in rows)
+
+
+def test_ingest_pipeline_in_mode67(tmp_path, dec67, synth67):
+    """PNG files of 1024x720 frames through the host ingest pool (libcimbar_ingest.so sizes its ring from cimbar_hip_geometry); a mode-B sized
+    file in the list is skipped like an unreadable one"""
+    from PIL import Image
+    from libcimbar_amd import ingest
+    payload, frames = F.clean_frames(synth67, 9, seed=12)
+    paths = []
+    for k in range(9):
+        p = tmp_path / f"m{k}.png"
+        Image.fromarray(frames[k]).save(p, compress_level=1)
+        paths.append(str(p))
+    Image.fromarray(np.zeros((1024, 1024, 3), np.uint8)).save(tmp_path / "square.png")
+    paths.insert(4, str(tmp_path / "square.png"))
+    ing = ingest.Ingest(dec67, threads=3, batch_frames=4, ring=2)
+    dec67.reset_ccm()
+    total, chunks, masks = ing.run_files(paths)
+    good = [k for k in range(10) if k != 4]
+    assert masks[4] == 0 and not chunks[4].any()
+    assert (masks[good] == 0xFFF).all() and (chunks[good] == payload).all() and total == 9 * GEO.FRAME_BYTES
+    dec67.reset_ccm()
+    total, chunks, masks = ing.run_raw(frames)
+    assert total == 9 * GEO.FRAME_BYTES and (chunks == payload).all()
+    ing.close()
