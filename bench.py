@@ -237,7 +237,20 @@ def extras(dec, dev, stream, n, outs, steps):
                              "pcie_GBs": round(m * modeb.FRAME_RGB_BYTES / best / 1e9, 2),
                              "note": "pageable host frames -> cimbar_ingest_run_raw: staging threads -> pinned ring (3 x 64 frames) -> H2D on a copy "
                                      "stream overlapped with cimbar_hip_decode_batch_pipelined -> D2H"}
+        hp = torch.from_numpy(host).pin_memory()
         del host
+        ing.run_raw_ptr(hp.data_ptr(), 64)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            total = ing.run_raw_ptr(hp.data_ptr(), m)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out["ingest_pinned"] = {"frames": m, "ms": round(best * 1e3, 3), "frames_per_s": round(m / best, 1), "good_bytes_ok": total == m * 7500,
+                                "pcie_GBs": round(m * modeb.FRAME_RGB_BYTES / best / 1e9, 2),
+                                "note": "page-locked host frames -> cimbar_ingest_run_raw: no staging, H2D straight from the caller's buffer on the copy "
+                                        "stream, overlapped with the pipelined decode and the D2H of the chunks"}
+        del hp
         with tempfile.TemporaryDirectory() as td:
             paths = []
             for k in range(128):

@@ -46,8 +46,9 @@ const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
 int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, int nfiles, int should_preprocess, int color_correction,
                                 cimbar_ingest_sink_fn sink, void* user);
 
-/* The same pipeline for frames that are already raw RGB8 in (pageable or pinned) host memory: staging into the pinned ring, H2D on the
- * copy stream, decode and D2H all overlapped. */
+/* The same pipeline for frames that are already raw RGB8 in host memory: pageable memory is staged into the pinned ring by the host threads;
+ * page-locked memory (hipHostMalloc / hipHostRegister) is copied to the device where it lies. H2D on the copy stream, decode and D2H all
+ * overlapped. */
 int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, int should_preprocess, int color_correction,
                               cimbar_ingest_sink_fn sink, void* user);
 

@@ -176,8 +176,10 @@ namespace {
 	} while (0)
 
 // fill(i, dst) produces frame i into dst (pinned memory) and says whether it is a usable frame
+// direct != nullptr: the frames already sit in page-locked host memory (hipHostMalloc / hipHostRegister) -- no staging threads, the H2D
+// copies read the caller's buffer
 template <typename FILL>
-int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_sink_fn sink, void* user, FILL fill)
+int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_sink_fn sink, void* user, FILL fill, const uint8_t* direct = nullptr)
 {
 	if (n <= 0) return 0;
 	ICHK(hipSetDevice(ing->device));
@@ -215,8 +217,12 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 		host_s += mine;
 	};
 	std::vector<std::thread> pool;
-	const int nthreads = ing->threads < n ? ing->threads : n;
+	const int nthreads = direct ? 0 : (ing->threads < n ? ing->threads : n);
 	for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+	if (direct) {
+		for (int k = 0; k < nbatch; ++k) filled[(size_t)k] = (k == nbatch - 1) ? n - k * B : B;
+		for (auto& sl : ing->slots) std::fill(sl.valid.begin(), sl.valid.end(), (uint8_t)1);
+	}
 
 	int64_t total = 0;
 	int rc = 0;
@@ -251,7 +257,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			cv.wait(lk, [&] { return filled[(size_t)k] == m; });
 			(void)t0;
 		}
-		hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
+		hipError_t e = hipMemcpyAsync(sl.d_in, direct ? direct + (size_t)k * B * ing->frame : sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
 		if (e != hipSuccess) { ing->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
 		// "the frames are whatever hip_stream has produced up to here": the library's own stream waits for the copy
 		int r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, ing->copy_stream);
@@ -378,7 +384,11 @@ int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, 
 {
 	if (!ing || !frames || n < 0) return CIMBAR_HIP_EINVAL;
 	auto fill = [&](int i, uint8_t* dst) -> bool { std::memcpy(dst, frames + (size_t)i * ing->frame, ing->frame); return true; };
-	return run_pipeline(ing, n, should_preprocess, color_correction, sink, user, fill);
+	// frames in page-locked memory (hipHostMalloc, hipHostRegister, torch's pin_memory) are copied to the device where they lie
+	hipPointerAttribute_t attr;
+	const bool pinned = hipPointerGetAttributes(&attr, frames) == hipSuccess && attr.type == hipMemoryTypeHost;
+	if (!pinned) (void)hipGetLastError();   // an ordinary pointer is reported as an error: clear it
+	return run_pipeline(ing, n, should_preprocess, color_correction, sink, user, fill, pinned ? frames : nullptr);
 }
 
 int cimbar_ingest_timings(const cimbar_ingest* ing, double out3[3])

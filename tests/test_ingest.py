@@ -95,6 +95,12 @@ def test_ingest_pipeline_equals_batch_decode(tmp_path, synth, hip_decoder):
     assert total == want_total and (masks == want_masks).all() and (chunks == want_chunks.reshape(21, -1)).all()
     t = ing.timings()
     assert t["wall_s"] > 0
+    # page-locked source: copied to the device where it lies (no staging threads)
+    import torch
+    pinned = torch.from_numpy(frames).pin_memory()
+    hip_decoder.reset_ccm()
+    total, chunks, masks = ing.run_raw(pinned.numpy())
+    assert total == want_total and (masks == want_masks).all() and (chunks == want_chunks.reshape(21, -1)).all()
     ing.close()
 
 
