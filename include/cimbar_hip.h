@@ -76,7 +76,13 @@ const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
  *   rgb        : height rows of `stride` bytes, width*3 used (RGB8, as cv::Mat CV_8UC3 after BGR2RGB, cimbar.cpp:132-133)
  *   chunks     : 12*625 bytes; slot j holds fountain chunk j of the frame, zero-filled if the chunk was dropped
  *   good_mask  : bit j set <=> aligned_stream delivered chunk j to the sink (aligned_stream.h:62-85)
- * Returns the reference's return value: cumulative good bytes = 625 * popcount(mask) (Decoder.h:116-117). */
+ * Returns the reference's return value: cumulative good bytes = 625 * popcount(mask) (Decoder.h:116-117).
+ * Image size, as CimbReader's constructor treats it (CimbReader.cpp:107-126):
+ *   width x height == image_size_x x image_size_y : the ordinary case (and the only one the batch entry points take);
+ *   larger in either direction : the grid sits _gridPadding = min(width - image_size_x, height - image_size_y) / 2 pixels in, in x and in y, and
+ *                                the threshold pass sees the real pixels around it (a single-image path, not tuned for throughput);
+ *   smaller : the reference reads no cell at all, Reed-Solomon then "decodes" its all-zero buffers and every chunk is delivered as zeros --
+ *             the call returns the full byte count, mask 0xFFF and zero-filled chunks, exactly like the reference (a fountain sink drops them). */
 int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
                             int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask);
 

@@ -104,7 +104,13 @@ public:
 	unsigned decode(const MAT& img, STREAM& ostream, bool should_preprocess = false, int color_correction = 2)
 	{
 		if (!_ctx) return 0;
-		if ((unsigned)img.cols != image_size_x() || (unsigned)img.rows != image_size_y()) { _rc = CIMBAR_HIP_EDIM; return 0; }
+		if ((unsigned)img.cols < image_size_x() || (unsigned)img.rows < image_size_y()) {
+			// CimbReader::_good == false (CimbReader.cpp:119): the reference writes its all-zero Reed-Solomon outputs
+			const std::vector<char> z(frame_bytes(), 0);
+			ostream.write(z.data(), frame_bytes());
+			return (unsigned)ostream.tellp();
+		}
+		if ((unsigned)img.cols != image_size_x() || (unsigned)img.rows != image_size_y()) { _rc = CIMBAR_HIP_EDIM; return 0; }   // (padded images: decode_fountain only)
 		std::vector<unsigned char> packed;
 		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
 		const size_t step = image_step(img), dense = (size_t)image_size_x() * 3;

@@ -169,7 +169,7 @@ void co_threshold_bitplane(const uint8_t* rgb, int w, int h, int preprocess, uin
 			}
 			rowsum[(size_t)y * w + x] = (uint16_t)acc;
 		}
-	memset(bitplane, 0, n / 8);
+	memset(bitplane, 0, (n + 7) / 8);   /* (the reference packs a trailing partial byte differently, bitmatrix.h:36-46: never inside the grid) */
 	for (int y = 0; y < h; ++y)
 		for (int x = 0; x < w; ++x) {
 			int acc = 0;
@@ -873,8 +873,30 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 	if (!ccm) ccm = &local;
 	memset(outbuf, 0, (size_t)CO_CHUNKS_PER_FRAME * CO_CHUNK);
 	if (good_mask) *good_mask = 0;
-	if (w != IMG_W || h != IMG_H) return -1;   /* restatement covers the deskewed image_size_x x image_size_y case only */
+	if (w < IMG_W || h < IMG_H) {
+		/* CimbReader::_good == false (CimbReader.cpp:119): done() at once, no cell is read. Decoder::do_decode (Decoder.h:81-117) still flushes its
+		 * zero-initialised symbol and colour buffers through Reed-Solomon; an all-zero block is a valid codeword (the colour pass writes every
+		 * cell's bits at bit 0 of the colour stream, one byte error at most, corrected), so every block "decodes" to zeros, aligned_stream
+		 * delivers all 12 chunks and the header stays id 0: the full byte count, chunks of zeros, CCM untouched. */
+		if (good_mask) *good_mask = (1u << CO_CHUNKS_PER_FRAME) - 1u;
+		if (block_ok) memset(block_ok, 1, SYM_BYTES / CO_RS_BLOCK + COL_BYTES / CO_RS_BLOCK);
+		return CO_CHUNKS_PER_FRAME * CO_CHUNK;
+	}
 	ensure_pos();
+	/* A larger image (CimbReader.cpp:112-117): the grid sits _gridPadding = min(cols - image_size_x, rows - image_size_y) / 2 pixels in, in x
+	 * and in y, and every later position -- cells, drift, the anchor centres of calculateWhite -- is relative to that origin. The threshold
+	 * runs over the WHOLE image (its borders are the large image's borders); a cell window never leaves the grid's image_size_x x image_size_y
+	 * window (offset 8 - 1 - 7 >= 0 ... ), so the window's bits and pixels, cut out, are all the rest of the decode ever reads. */
+	uint8_t* crop = NULL;
+	uint8_t* full_plane = NULL;
+	const int pad = ((w - IMG_W) < (h - IMG_H) ? (w - IMG_W) : (h - IMG_H)) / 2;
+	if (w != IMG_W || h != IMG_H) {
+		full_plane = (uint8_t*)malloc(((size_t)w * h + 7) / 8);
+		co_threshold_bitplane(rgb, w, h, preprocess, full_plane);
+		crop = (uint8_t*)malloc((size_t)IMG_W * IMG_H * 3);
+		for (int y = 0; y < IMG_H; ++y) memcpy(crop + (size_t)y * IMG_W * 3, rgb + ((size_t)(y + pad) * w + pad) * 3, (size_t)IMG_W * 3);
+		rgb = crop;
+	}
 
 	static uint32_t rev[NCELLS];
 	static int rev_init = 0;
@@ -882,7 +904,15 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 
 	/* CimbReader ctor, CimbReader.cpp:107-126 */
 	uint8_t* bitplane = (uint8_t*)malloc((size_t)IMG_W * IMG_H / 8);
-	co_threshold_bitplane(rgb, IMG_W, IMG_H, preprocess, bitplane);
+	if (full_plane) {
+		memset(bitplane, 0, (size_t)IMG_W * IMG_H / 8);
+		for (int y = 0; y < IMG_H; ++y)
+			for (int x = 0; x < IMG_W; ++x) {
+				const size_t src = (size_t)(y + pad) * w + (x + pad), dst = (size_t)y * IMG_W + x;
+				if (full_plane[src >> 3] & (0x80 >> (src & 7))) bitplane[dst >> 3] |= (uint8_t)(0x80 >> (dst & 7));
+			}
+		free(full_plane);
+	} else co_threshold_bitplane(rgb, IMG_W, IMG_H, preprocess, bitplane);
 	if (color_correction == 1) {
 		float white[3];
 		calculate_white(rgb, white);
@@ -932,6 +962,7 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 		if (plain) { if (r > 0) memcpy(outbuf + (size_t)nblock * CO_RS_DATA, out, CO_RS_DATA); if (block_ok) block_ok[nblock] = r > 0; }
 		else aligner_block(&al, r > 0, out, &md, outbuf, good_mask ? good_mask : &dummy_mask);
 	}
+	free(crop);
 	return plain ? nblock * CO_RS_DATA : (int)al.total;
 }
 

@@ -79,9 +79,12 @@ int main(int argc, char** argv)
 	cimbar_amd::image_view img0{frames.data(), 1024, 1024, 0};
 	CHECK(dec.decode_fountain(img0, wrong) == 7500 && wrong.bytes.empty());
 
-	// wrong geometry: like CimbReader::_good == false -> 0 bytes (CimbReader.cpp:119,164-167)
+	// an image smaller than the frame: CimbReader::_good == false (CimbReader.cpp:119) -> no cell is read, and the reference's Reed-Solomon pass
+	// then delivers its all-zero buffers as twelve chunks of zeros with the full byte count; same here
 	cimbar_amd::image_view small{frames.data(), 512, 512, 512 * 3};
-	CHECK(dec.decode_fountain(small, sink2) == 0 && dec.error_code() == CIMBAR_HIP_EDIM);
+	collecting_sink zeros(625);
+	CHECK(dec.decode_fountain(small, zeros) == 7500 && zeros.bytes.size() == 7500);
+	for (unsigned char b : zeros.bytes) CHECK(b == 0);
 
 	// the stage in front (Deskewer.h:26-40, Scanner.h:148-165): paste frame 0 upright into a dark 1920x1080 capture, deskew it from the
 	// anchor centres of that paste, decode the result
@@ -136,7 +139,7 @@ int main(int argc, char** argv)
 		for (int f = 0; f < n; ++f) {
 			cimbar_amd::image_view img{f67.data() + FM * f, 1024, 720, 1024 * 3};
 			CHECK(mini.decode_fountain(img, s67) == 5148);
-			CHECK(dec.decode_fountain(img, wrong) == 0 && dec.error_code() == CIMBAR_HIP_EDIM);   // a mode-B decoder refuses the 1024x720 frame
+			CHECK(dec.decode_fountain(img, wrong) == 7500 && wrong.bytes.size() == 7500ull * (f + 1) && wrong.bytes[7500ull * f + 17] == 0);   // "too small" for mode B: zero chunks, like the reference
 		}
 		CHECK(s67.bytes.size() == p67.size() && std::memcmp(s67.bytes.data(), p67.data(), p67.size()) == 0);
 		collecting_sink b67(429);
