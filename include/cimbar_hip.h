@@ -148,7 +148,7 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
  * 1080p capture instead of 6 MB), and its four corners come back for the warp, whose output can stay in device memory for
  * cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated, see DESIGN.md.
  *   cimbar_hip_scan_preprocess : n captures -> n * width * height bytes (0 / 255) = Scanner::preprocess_image(img, fast = true);
- *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Short side >= 2500 px (9x9 blur): EDIM.
+ *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Blur unit as in Scanner.h:157-159 (3x3 below 1500 px on the short side, 5x5 below 2500, 9x9 below 4500); 4500 px and more: EDIM.
  *   cimbar_hip_deskew_batch    : corners = n * 8 floats in HOST memory, per capture top-left, top-right, bottom-left, bottom-right (x, y)
  *                                exactly as Corners::all() returns them (Corners.h:45-53); frames = n * 1024*1024*3 bytes = what
  *                                Deskewer(0, {1024,1024}, 30).deskew(img, corners) returns.

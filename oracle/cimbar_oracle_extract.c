@@ -44,10 +44,13 @@ int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out)
 	const size_t n = (size_t)w * h;
 	unsigned unit = (unsigned)(w < h ? w : h);
 	unit = next_pow2_plus_one((unsigned)(unit * 0.002));
-	if (unit != 3 && unit != 5) return -1;
-	const int r = (int)unit / 2, shift = r == 1 ? 4 : 8;
-	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1};
-	const int* k = r == 1 ? k3 : k5;
+	if (unit != 3 && unit != 5 && unit != 9) return -1;   /* (17 and up: captures of 4500 px and more on the short side) */
+	/* ksize 9: getGaussianKernel(9, sigma <= 0) -> sigma = 0.3*((9-1)*0.5 - 1) + 0.8 = 1.7, exp(-x^2 / (2 sigma^2)) normalised, then the 8.8 fixed-point
+ * weights of getGaussianKernelFixedPoint_ED (round outside-in with the error carried, centre = 256 - the rest): 256 * k = 3.80 12.75 30.29 50.90
+ * 60.51 -> {4, 13, 30, 51, 60, 51, 30, 13, 4} (plain rounding gives the same, no value is near a half), s = 16 [assumed-OpenCV] */
+	const int r = (int)unit / 2, shift = r == 1 ? 4 : (r == 2 ? 8 : 16);
+	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
+	const int* k = r == 1 ? k3 : (r == 2 ? k5 : k9);
 
 	uint8_t* gray = (uint8_t*)malloc(n);
 	int* hs = (int*)malloc(n * sizeof(int));
