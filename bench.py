@@ -271,26 +271,28 @@ def extras(dec, dev, stream, n, outs, steps):
         ing.close()
     except Exception as e:
         out["ingest"] = {"error": repr(e)}
-    # ---- mode 67 ("Bm", Conf8x8_mini: 1024x720 frames, 12 x 429 bytes): the same kernels compiled for the other geometry, its own context
-    try:
+    # ---- modes 67 ("Bm", Conf8x8_mini: 1024x720 frames, 12 x 429 bytes) and 66 ("Bu", Conf8x8_micro: 736x637, 6 x 540): the same kernels
+    # compiled for the other geometries, each with its own context
+    for other in (67, 66):
+      try:
         from libcimbar_amd import HipDecoder, geometry
-        g = geometry.for_mode(67)
-        d67 = HipDecoder(dec.device, 67)
-        payload = framegen.synth_payload(n, seed=6767, device=dev, mode=67)
+        g = geometry.for_mode(other)
+        d67 = HipDecoder(dec.device, other)
+        payload = framegen.synth_payload(n, seed=6767, device=dev, mode=other)
         f67 = torch.empty((n, *g.FRAME_SHAPE), dtype=torch.uint8, device=dev)
         d67.encode_batch_device(payload.data_ptr(), n, f67.data_ptr())
         o67 = [(torch.zeros((n, g.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(d67.pipeline_depth)]
         ms_p = stream_ms(d67, [f67], o67, steps, 4, True, stream, dev)
-        ok = all(bool((m == 0xFFF).all().item()) and bool((c == payload).all().item()) for c, m in o67)
+        ok = all(bool((m == g.FULL_MASK).all().item()) and bool((c == payload).all().item()) for c, m in o67)
         st = stage_times(d67, f67, o67[0], stream, dev, reps=3)
         alg = n * (g.FRAME_RGB_BYTES + g.FRAME_BYTES + 4)
-        out["mode67"] = {"frames": n, "frame": "1024x720", "ms_per_step": round(ms_p, 4), "frames_per_s": round(n / ms_p * 1e3, 1), "payload_ok": ok,
-                         "whole_path_hbm_frac": round(alg / (ms_p * 1e-3) / 8e12, 4), "threshold_hbm_frac": round(alg / (st["threshold"] * 1e-3) / 8e12, 4),
-                         "stage_ms": {k: round(v, 4) for k, v in st.items()}}
+        out["mode%d" % other] = {"frames": n, "frame": "%dx%d" % (g.IMG_W, g.IMG_H), "ms_per_step": round(ms_p, 4), "frames_per_s": round(n / ms_p * 1e3, 1),
+                                 "payload_ok": ok, "whole_path_hbm_frac": round(alg / (ms_p * 1e-3) / 8e12, 4),
+                                 "threshold_hbm_frac": round(alg / (st["threshold"] * 1e-3) / 8e12, 4), "stage_ms": {k: round(v, 4) for k, v in st.items()}}
         del f67, o67
         d67.close()
-    except Exception as e:
-        out["mode67"] = {"error": repr(e)}
+      except Exception as e:
+        out["mode%d" % other] = {"error": repr(e)}
     try:
         from libcimbar_amd import extractbench
         out.update(extractbench.run(dec, dev, stream, synth))

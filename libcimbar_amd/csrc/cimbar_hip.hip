@@ -46,6 +46,11 @@
 #include "mode.hip.inc"
 #undef CIMBAR_MODE
 #undef CIMBAR_NS
+#define CIMBAR_MODE 66
+#define CIMBAR_NS m66
+#include "mode.hip.inc"
+#undef CIMBAR_MODE
+#undef CIMBAR_NS
 
 #include "api.hip.inc"
 #include "comm.hip.inc"

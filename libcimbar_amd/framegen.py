@@ -138,11 +138,12 @@ def synth_payload(n_frames, seed=1234, encode_id=1, file_size=None, first_block=
     Headers follow FountainMetadata.h:18-24 with consecutive block ids, so CimbReader::update_metadata's prediction
     (CimbReader.cpp:269-280) holds and the colour-correction path is exercised the same way as on a real stream."""
     geo = geometry.for_mode(mode)
+    per = geo.CHUNKS_PER_FRAME
     if file_size is None:
-        file_size = n_frames * 12 * (geo.CHUNK - 6)
+        file_size = n_frames * per * (geo.CHUNK - 6)
     g = np.random.default_rng(seed)
-    chunks = g.integers(0, 256, size=(n_frames * 12, geo.CHUNK), dtype=np.uint8)
-    ids = (np.arange(n_frames * 12) + first_block) & 0xFFFF
+    chunks = g.integers(0, 256, size=(n_frames * per, geo.CHUNK), dtype=np.uint8)
+    ids = (np.arange(n_frames * per) + first_block) & 0xFFFF
     chunks[:, 0] = (encode_id & 0x7F) | ((file_size >> 17) & 0x80)
     chunks[:, 1] = (file_size >> 16) & 0xFF
     chunks[:, 2] = (file_size >> 8) & 0xFF

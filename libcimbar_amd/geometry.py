@@ -1,5 +1,6 @@
 """The grid of a cimbar mode, host side: what the reference keeps in cimbar::conf (GridConf.h:9-72) and reads through Config:: getters
-(Config.h:52-165). Modes built into the HIP library: 68 ("B", Conf8x8, GridConf.h:121-142) and 67 ("Bm", Conf8x8_mini, GridConf.h:168-189).
+(Config.h:52-165). Modes built into the HIP library: 68 ("B", Conf8x8, GridConf.h:121-142), 67 ("Bm", Conf8x8_mini, GridConf.h:168-189) and
+66 ("Bu", Conf8x8_micro, GridConf.h:144-166).
 `modeb` is the mode-68 instance spelled out as module constants; tests/test_modeb_tables.py checks the two agree.
 """
 from dataclasses import dataclass
@@ -7,9 +8,10 @@ from dataclasses import dataclass
 import numpy as np
 
 _CONF = {
-    # mode: (image_size_x, image_size_y, cell_offset, cells_per_col_x, cells_per_col_y, ecc_block_size, ecc_bytes)
-    68: (1024, 1024, 8, 112, 112, 155, 30),
-    67: (1024, 720, 9, 112, 78, 179, 36),
+    # mode: (image_size_x, image_size_y, cell_offset, cells_per_col_x, cells_per_col_y, ecc_block_size, ecc_bytes, fountain_chunks_scalar)
+    68: (1024, 1024, 8, 112, 112, 155, 30, 2),
+    67: (1024, 720, 9, 112, 78, 179, 36, 2),
+    66: (736, 637, 9, 80, 69, 168, 33, 1),
 }
 
 
@@ -28,7 +30,7 @@ class Geometry:
     MARKER: int = 6                # lrint(54 / 9), GridConf.h:32-40
     SYMBOL_BITS: int = 4
     COLOR_BITS: int = 2
-    CHUNKS_PER_FRAME: int = 12     # fountain_chunks_per_frame = bits_per_cell * fountain_chunks_scalar(2), GridConf.h:54-61
+    CHUNKS_PER_FRAME: int = 12     # fountain_chunks_per_frame = bits_per_cell * fountain_chunks_scalar (2; micro: 1), GridConf.h:54-61
 
     # ---- derived (GridConf.h:42-71)
     @property
@@ -58,7 +60,9 @@ class Geometry:
     @property
     def FRAME_SHAPE(self): return (self.IMG_H, self.IMG_W, 3)
     @property
-    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz"}[self.MODE]
+    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz", 66: "modebu_template.npz"}[self.MODE]
+    @property
+    def FULL_MASK(self): return (1 << self.CHUNKS_PER_FRAME) - 1
 
     def cell_positions(self):
         """(NCELLS, 2) int32 top-left pixel (x, y) of every cell in linear order (CellPositions.cpp:5-51)."""
@@ -88,6 +92,6 @@ def for_mode(mode=68):
     """Config::temp_conf(mode_val) for the modes the HIP library is built for (0 = the default, mode B)."""
     mode = 68 if mode in (0, None) else int(mode)
     if mode not in _CONF:
-        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm')")
-    w, h, off, dx, dy, blk, par = _CONF[mode]
-    return Geometry(mode, w, h, off, dx, dy, blk, par)
+        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm', 66 'Bu')")
+    w, h, off, dx, dy, blk, par, scalar = _CONF[mode]
+    return Geometry(mode, w, h, off, dx, dy, blk, par, CHUNKS_PER_FRAME=6 * scalar)

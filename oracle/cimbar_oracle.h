@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* One geometry per build of the oracle (cc -DCO_MODE=67 -> libcimbar_oracle_m67.so), Config.h:19-44 + GridConf.h:121-186:
- * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"). */
+ * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"), 66 = Conf8x8_micro ("Bu"). */
 #ifndef CO_MODE
 #define CO_MODE 68
 #endif
@@ -33,6 +33,7 @@ extern "C" {
 #define CO_DIM_Y 112
 #define CO_RS_BLOCK 155
 #define CO_RS_PARITY 30
+#define CO_CHUNKS_PER_FRAME 12
 #elif CO_MODE == 67
 #define CO_IMG_W 1024
 #define CO_IMG_H 720
@@ -41,12 +42,21 @@ extern "C" {
 #define CO_DIM_Y 78
 #define CO_RS_BLOCK 179
 #define CO_RS_PARITY 36
+#define CO_CHUNKS_PER_FRAME 12
+#elif CO_MODE == 66                                                /* Conf8x8_micro ("Bu"), GridConf.h:144-166: fountain_chunks_scalar 1 */
+#define CO_IMG_W 736
+#define CO_IMG_H 637
+#define CO_OFFSET 9
+#define CO_DIM_X 80
+#define CO_DIM_Y 69
+#define CO_RS_BLOCK 168
+#define CO_RS_PARITY 33
+#define CO_CHUNKS_PER_FRAME 6
 #else
-#error "CO_MODE must be 68 or 67"
+#error "CO_MODE must be 68, 67 or 66"
 #endif
 #define CO_CELLS (CO_DIM_X * CO_DIM_Y - 4 * 6 * 6)               /* 12400 | 8592 */
-#define CO_CHUNKS_PER_FRAME 12
-#define CO_RS_DATA (CO_RS_BLOCK - CO_RS_PARITY)                  /* 125 | 143 */
+#define CO_RS_DATA (CO_RS_BLOCK - CO_RS_PARITY)                  /* 125 | 143 | 135 */
 #define CO_CHUNK (CO_CELLS * 6 / 8 / CO_RS_BLOCK * CO_RS_DATA / CO_CHUNKS_PER_FRAME)   /* 625 | 429 */
 
 /* the constants above, for the tests: {mode, image w, image h, cells, chunk bytes, RS block, RS parity, cells per row, cell rows, cell offset} */

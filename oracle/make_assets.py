@@ -23,7 +23,7 @@ def main():
     if L is None:
         raise SystemExit("oracle/_ref/libcimbar_ref.so missing: run `make -C oracle ref` first")
     os.makedirs(os.path.join(ROOT, "libcimbar_amd", "data"), exist_ok=True)
-    for mode, (w, h), name in ((68, (1024, 1024), "modeb_template.npz"), (67, (1024, 720), "modebm_template.npz")):
+    for mode, (w, h), name in ((68, (1024, 1024), "modeb_template.npz"), (67, (1024, 720), "modebm_template.npz"), (66, (736, 637), "modebu_template.npz")):
         L.ref_configure(mode)
         t = np.zeros(w * h * 3, np.uint8)
         L.ref_template_frame(P(t))

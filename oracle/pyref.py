@@ -25,8 +25,9 @@ def P(a):
 _oracle = {}
 _ref = None
 
-# mode -> (image w, image h, cells, chunk bytes, RS blocks per frame, RS data bytes per block): Config.h:101-165 for the two modes the oracle is built for
-GEOMETRY = {68: (1024, 1024, 12400, 625, 60, 125), 67: (1024, 720, 8592, 429, 36, 143)}
+# mode -> (image w, image h, cells, chunk bytes, RS blocks per frame, RS data bytes per block, chunks per frame): Config.h:101-165 for the modes
+# the oracle is built for
+GEOMETRY = {68: (1024, 1024, 12400, 625, 60, 125, 12), 67: (1024, 720, 8592, 429, 36, 143, 12), 66: (736, 637, 5376, 540, 24, 135, 6)}
 
 
 def oracle_so(mode=68):
@@ -44,7 +45,7 @@ def build_oracle(mode=68):
 
 
 def oracle_lib(mode=68):
-    """The C restatement built for one mode (68 = "B", 67 = "Bm"): one geometry per library, see cimbar_oracle.h."""
+    """The C restatement built for one mode (68 = "B", 67 = "Bm", 66 = "Bu"): one geometry per library, see cimbar_oracle.h."""
     if mode not in _oracle:
         L = ctypes.CDLL(build_oracle(mode))
         L.co_last_symbols.restype = ctypes.POINTER(ctypes.c_uint8)
@@ -89,7 +90,7 @@ def oracle_decode(rgb, preprocess=0, cc=2, ccm=None, mode=68):
     """co_decode_fountain on one (h,w,3) uint8 frame of `mode` -> (good_bytes, chunks (12,chunk), mask, ccm struct)."""
     L = oracle_lib(mode)
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-    chunks = np.zeros((12, GEOMETRY[mode][3]), np.uint8)
+    chunks = np.zeros((GEOMETRY[mode][6], GEOMETRY[mode][3]), np.uint8)
     mask = ctypes.c_uint32(0)
     if ccm is None:
         ccm = CoCcm()
@@ -133,7 +134,7 @@ def ref_decode(rgb, preprocess=0, cc=2, reset_ccm=1, mode=68):
     """the caller has selected `mode` with ref_mode() already; it only sizes the chunk slots here"""
     L = ref_lib()
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-    chunks = np.zeros((12, GEOMETRY[mode][3]), np.uint8)
+    chunks = np.zeros((GEOMETRY[mode][6], GEOMETRY[mode][3]), np.uint8)
     mask = ctypes.c_uint32(0)
     r = L.ref_decode_fountain(P(rgb), rgb.shape[1], rgb.shape[0], int(preprocess), int(cc), int(reset_ccm), P(chunks), ctypes.byref(mask))
     return r, chunks, mask.value

@@ -1,0 +1,115 @@
+"""The other 8x8 modes, no GPU: 67 ("Bm", Conf8x8_mini: 1024x720, 112x78 cells, RS(179,143), 12 chunks x 429 bytes; GridConf.h:168-189) and 66
+("Bu", Conf8x8_micro: 736x637, 80x69 cells, RS(168,135), 6 chunks x 540 bytes; GridConf.h:144-166). The oracle built for each geometry
+(oracle/libcimbar_oracle_m67.so / _m66.so, -DCO_MODE=..) against the reference build and against the committed golden vectors the reference
+build produced (tests/golden/mode67.json, mode66.json), plus the host-side geometry tables."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from libcimbar_amd import framegen, geometry, modeb
+from oracle import pyref
+from oracle.make_golden_modes import cases
+from oracle.pyref import P
+from tests import frames as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# by hand from GridConf.h: total_cells, RS blocks (symbol + colour), chunk size = capacity(6) * (block - ecc) / block / chunks per frame
+EXPECT = {67: dict(NCELLS=8592, BLOCKS=36, SYM_BLOCKS=24, COL_BLOCKS=12, CHUNK=429, FRAME_BYTES=5148, CHUNKS_PER_FRAME=12),
+          66: dict(NCELLS=5376, BLOCKS=24, SYM_BLOCKS=16, COL_BLOCKS=8, CHUNK=540, FRAME_BYTES=3240, CHUNKS_PER_FRAME=6)}
+
+
+@pytest.fixture(scope="module", params=[67, 66])
+def MODE(request):
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def synth67(MODE):
+    return framegen.FrameSynth("cpu", MODE)
+
+
+@pytest.fixture(scope="module")
+def FIX(MODE):
+    return json.load(open(os.path.join(HERE, "golden", "mode%d.json" % MODE)))
+
+
+def test_geometry_tables(MODE):
+    b = geometry.for_mode(68)
+    for name in ("NCELLS", "RS_BLOCK", "RS_PARITY", "RS_DATA", "SYM_BLOCKS", "COL_BLOCKS", "CHUNK", "FRAME_BYTES", "TOP_W", "TOP_CELLS", "MID_CELLS", "OFFSET"):
+        assert getattr(b, name) == getattr(modeb, name), name
+    assert (b.cell_positions() == modeb.cell_positions()).all() and (b.interleave_indices() == modeb.interleave_indices()).all()
+    m = geometry.for_mode(MODE)
+    for name, want in EXPECT[MODE].items():
+        assert getattr(m, name) == want, name
+    o = (ctypes.c_int32 * 10)()
+    pyref.oracle_lib(MODE).co_geometry(o)
+    assert list(o) == [MODE, m.IMG_W, m.IMG_H, m.NCELLS, m.CHUNK, m.RS_BLOCK, m.RS_PARITY, m.DIM_X, m.DIM_Y, m.OFFSET]
+    xy = np.zeros((m.NCELLS, 2), np.int32)
+    pyref.oracle_lib(MODE).co_cell_positions(P(xy))
+    assert (xy == m.cell_positions()).all()
+    with pytest.raises(ValueError):
+        geometry.for_mode(4)
+
+
+def test_golden_vectors_replay_on_the_oracle(MODE, synth67, FIX):
+    """the reference build's outputs in this mode (committed), reproduced by the C restatement built for it"""
+    ccm = pyref.CoCcm()
+    rows = FIX["frames"]
+    items = cases(synth67)
+    assert len(items) == len(rows)
+    for (nm, pre, fr), row in zip(items, rows):
+        assert nm == row["name"] and pre == row["preprocess"]
+        assert hashlib.sha256(np.ascontiguousarray(fr).tobytes()).hexdigest() == row["frame_sha256"], f"{nm}: the input frame changed"
+        r, chunks, mask, ccm = pyref.oracle_decode(fr, pre, 2, ccm, mode=MODE)
+        assert (r, mask) == (row["good_bytes"], row["mask"]), nm
+        assert hashlib.sha256(chunks.tobytes()).hexdigest() == row["chunks_sha256"], nm
+    full = geometry.for_mode(MODE).FULL_MASK
+    assert sum(r["mask"] == full for r in rows) >= 8 and any(0 < r["mask"] < full for r in rows) and any(r["mask"] == 0 for r in rows)
+
+
+def test_framegen_matches_the_reference_encoder(ref, MODE, synth67):
+    payload, frames = F.clean_frames(synth67, 3, seed=5)
+    with pyref.ref_mode(MODE):
+        for k in range(3):
+            assert (pyref.ref_encode_raw(payload[k], MODE) == frames[k]).all()
+
+
+@pytest.mark.parametrize("pre,cc", [(0, 2), (1, 2), (0, 1), (0, 0)])
+def test_oracle_matches_the_reference_build(ref, MODE, synth67, pre, cc):
+    items = F.distorted_set(synth67, seed=11)
+    ccm = pyref.CoCcm()
+    O = pyref.oracle_lib(MODE)
+    g = geometry.for_mode(MODE)
+    with pyref.ref_mode(MODE):
+        for k, (nm, fr) in enumerate(items):
+            r, chunks, mask = pyref.ref_decode(fr, pre, cc, reset_ccm=(k == 0), mode=MODE)
+            r2, chunks2, mask2, ccm = pyref.oracle_decode(fr, pre, cc, ccm, mode=MODE)
+            assert (r, mask) == (r2, mask2) and (chunks == chunks2).all(), nm
+            # stage level: the flood-ordered symbol pass
+            vis = np.zeros((g.NCELLS, 4), np.int32)
+            assert ref.ref_symbol_pass(P(np.ascontiguousarray(fr)), g.IMG_W, g.IMG_H, pre, None, P(vis)) == g.NCELLS
+            bp = np.zeros(g.IMG_W * g.IMG_H // 8, np.uint8)
+            O.co_threshold_bitplane(P(np.ascontiguousarray(fr)), g.IMG_W, g.IMG_H, pre, P(bp))
+            vis2 = np.zeros((g.NCELLS, 4), np.int32)
+            assert O.co_symbol_pass(P(bp), P(vis2), None) == g.NCELLS
+            assert (vis == vis2).all(), nm
+
+
+def test_extract_stage_matches_the_reference_build(ref, MODE, synth67):
+    """Extractor::extract with the mode's own target size (Extractor.cpp:6-13, Deskewer.h:26-40) on a 1080p capture"""
+    g = geometry.for_mode(MODE)
+    payload, frames = F.clean_frames(synth67, 1, seed=21)
+    quad = {67: ((300, 150), (1600, 170), (290, 930), (1620, 915)), 66: ((400, 60), (1500, 75), (395, 1010), (1510, 1000))}[MODE]
+    cam = np.ascontiguousarray(F.camera_frame(frames[0], quad=quad, background=20))
+    h, w = cam.shape[:2]
+    a, b = np.zeros(g.FRAME_SHAPE, np.uint8), np.zeros(g.FRAME_SHAPE, np.uint8)
+    with pyref.ref_mode(MODE):
+        ra = ref.ref_extract(P(cam), w, h, P(a))
+        r, chunks, mask = pyref.ref_decode(a, 1 if ra == 2 else 0, 2, mode=MODE)
+    rb = pyref.oracle_lib(MODE).co_extract(P(cam), w, h, P(b), None)
+    assert ra == rb and ra != 0 and (a == b).all()
+    assert mask == g.FULL_MASK and (chunks.reshape(-1) == payload[0]).all()

@@ -8,7 +8,7 @@ from libcimbar_amd import framegen
 from oracle import pyref
 from tests import frames as F
 
-SIZES = {68: (1024, 1024), 67: (1024, 720)}
+SIZES = {68: (1024, 1024), 67: (1024, 720), 66: (736, 637)}
 EXTRA = [(16, 16), (10, 30), (7, 3), (64, 0), (1, 1), (0, 9), (301, 57)]
 
 
@@ -32,7 +32,7 @@ def padded_cases(mode, seed=3):
     return out
 
 
-@pytest.mark.parametrize("mode", [68, 67])
+@pytest.mark.parametrize("mode", [68, 67, 66])
 def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
     w, h = SIZES[mode]
     with pyref.ref_mode(mode):
@@ -46,11 +46,11 @@ def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
             small = np.random.default_rng(1).integers(0, 256, shape, dtype=np.uint8)
             r, ch, m = pyref.ref_decode(small, 0, 2, mode=mode)
             r2, ch2, m2, _ = pyref.oracle_decode(small, 0, 2, None, mode=mode)
-            assert (r, m) == (r2, m2) == (12 * ch.shape[1], 0xFFF) and not ch.any() and not ch2.any()
+            assert (r, m) == (r2, m2) == (ch.shape[0] * ch.shape[1], (1 << ch.shape[0]) - 1) and not ch.any() and not ch2.any()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [68, 67])
+@pytest.mark.parametrize("mode", [68, 67, 66])
 def test_gpu_padded_and_small_images_match_oracle(mode):
     import torch
     if not torch.cuda.is_available():
@@ -66,7 +66,7 @@ def test_gpu_padded_and_small_images_match_oracle(mode):
             r, ch, m = dec.decode_frame(big, should_preprocess=pre, color_correction=2)
             r2, ch2, m2, ccm = pyref.oracle_decode(big, pre, 2, ccm, mode=mode)
             assert (r, m) == (r2, m2) and (ch == ch2).all(), (nm, pre)
-            decoded += m == 0xFFF
+            decoded += m == dec.geo.FULL_MASK
         assert decoded >= len(EXTRA)
     # row stride larger than the row, and a too-small image
     nm, big = padded_cases(mode)[3]
@@ -75,12 +75,12 @@ def test_gpu_padded_and_small_images_match_oracle(mode):
     view = wide[:, :big.shape[1]]                 # same pixels, stride = (w + 5) * 3
     lib, ctx = dec._lib, dec._ctx
     import ctypes
-    chunks = np.zeros((12, dec.geo.CHUNK), np.uint8)
+    chunks = np.zeros((dec.geo.CHUNKS_PER_FRAME, dec.geo.CHUNK), np.uint8)
     mask = ctypes.c_uint32(0)
     dec.reset_ccm()
     r = lib.cimbar_hip_decode_frame(ctx, view.ctypes.data, view.shape[1], view.shape[0], view.strides[0], 0, 2, chunks.ctypes.data, ctypes.byref(mask))
     r2, ch2, m2, _ = pyref.oracle_decode(big, 0, 2, None, mode=mode)
     assert (r, mask.value) == (r2, m2) and (chunks == ch2).all()
     r, ch, m = dec.decode_frame(np.full((h - 1, w, 3), 9, np.uint8))
-    assert (r, m) == (dec.geo.FRAME_BYTES, 0xFFF) and not ch.any()
+    assert (r, m) == (dec.geo.FRAME_BYTES, dec.geo.FULL_MASK) and not ch.any()
     dec.close()
