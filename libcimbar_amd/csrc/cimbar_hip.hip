@@ -51,6 +51,11 @@
 #include "mode.hip.inc"
 #undef CIMBAR_MODE
 #undef CIMBAR_NS
+#define CIMBAR_MODE 4
+#define CIMBAR_NS m4
+#include "mode.hip.inc"
+#undef CIMBAR_MODE
+#undef CIMBAR_NS
 
 #include "api.hip.inc"
 #include "comm.hip.inc"

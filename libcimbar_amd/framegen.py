@@ -86,7 +86,7 @@ class FrameSynth:
         template[z["idx"]] = z["val"]
         self.template = torch.from_numpy(template.reshape(g.FRAME_SHAPE)).to(self.device)
         masks = torch.from_numpy(modeb.tile_masks()).to(self.device)                      # (16,8,8) bool
-        pal = torch.from_numpy(modeb.PALETTE).to(self.device)                             # (4,3)
+        pal = torch.from_numpy(g.PALETTE).to(self.device)                                 # (4,3)
         # tile[colour*16 + symbol] (64,8,8,3): Common.cpp:150-171
         self.tiles = (masks[None, :, :, :, None] * pal[:, None, None, None, :]).reshape(64, 8, 8, 3).to(torch.uint8)
         self.stream_cell = torch.from_numpy(g.interleave_indices().astype(np.int64)).to(self.device)
@@ -100,6 +100,14 @@ class FrameSynth:
         payload = payload.to(self.device)
         f = payload.shape[0]
         blocks = rs_encode(payload.reshape(f * g.BLOCKS, g.RS_DATA), g.RS_PARITY).reshape(f, g.BLOCKS * g.RS_BLOCK).to(torch.int64)
+        if g.LEGACY:
+            # Encoder::encode_next_coupled (Encoder.h:131-163): the RS-encoded stream read 6 bits at a time, stream cell s = colour(2) | symbol(4)
+            bits = ((blocks[:, :, None] >> torch.arange(7, -1, -1, device=self.device)) & 1).reshape(f, g.NCELLS, 6)
+            w6 = torch.tensor([32, 16, 8, 4, 2, 1], device=self.device)
+            tiles_stream = (bits * w6).sum(dim=2)                                           # = colour * 16 + symbol
+            out = torch.empty_like(tiles_stream)
+            out[:, self.stream_cell] = tiles_stream
+            return out
         sym = blocks[:, :g.SYM_BLOCKS * g.RS_BLOCK]                                        # (F,6200)
         col = blocks[:, g.SYM_BLOCKS * g.RS_BLOCK:]                                        # (F,3100)
         sym_cells = torch.stack([sym >> 4, sym & 15], dim=2).reshape(f, g.NCELLS)           # stream order, high nibble first

@@ -1,6 +1,6 @@
 """The grid of a cimbar mode, host side: what the reference keeps in cimbar::conf (GridConf.h:9-72) and reads through Config:: getters
 (Config.h:52-165). Modes built into the HIP library: 68 ("B", Conf8x8, GridConf.h:121-142), 67 ("Bm", Conf8x8_mini, GridConf.h:168-189) and
-66 ("Bu", Conf8x8_micro, GridConf.h:144-166).
+66 ("Bu", Conf8x8_micro, GridConf.h:144-166), and the legacy 4-colour mode 4 ("4C", Config.h:24-29: Conf8x8 with the coupled decode).
 `modeb` is the mode-68 instance spelled out as module constants; tests/test_modeb_tables.py checks the two agree.
 """
 from dataclasses import dataclass
@@ -12,6 +12,7 @@ _CONF = {
     68: (1024, 1024, 8, 112, 112, 155, 30, 2),
     67: (1024, 720, 9, 112, 78, 179, 36, 2),
     66: (736, 637, 9, 80, 69, 168, 33, 1),
+    4: (1024, 1024, 8, 112, 112, 155, 30, -10),     # Config.h:24-29: Conf8x8 + legacy_mode, fountain_chunks_scalar -10 = ten chunks per frame
 }
 
 
@@ -31,6 +32,7 @@ class Geometry:
     SYMBOL_BITS: int = 4
     COLOR_BITS: int = 2
     CHUNKS_PER_FRAME: int = 12     # fountain_chunks_per_frame = bits_per_cell * fountain_chunks_scalar (2; micro: 1), GridConf.h:54-61
+    LEGACY: bool = False           # legacy_mode (Config.h:24-35): symbol and colour bits coupled in ONE Reed-Solomon stream, colour_mode 0 palette
 
     # ---- derived (GridConf.h:42-71)
     @property
@@ -44,9 +46,10 @@ class Geometry:
     @property
     def RS_DATA(self): return self.RS_BLOCK - self.RS_PARITY
     @property
-    def SYM_BLOCKS(self): return self.NCELLS * self.SYMBOL_BITS // 8 // self.RS_BLOCK
+    def SYM_BLOCKS(self):
+        return self.NCELLS * (self.SYMBOL_BITS + self.COLOR_BITS) // 8 // self.RS_BLOCK if self.LEGACY else self.NCELLS * self.SYMBOL_BITS // 8 // self.RS_BLOCK
     @property
-    def COL_BLOCKS(self): return self.NCELLS * self.COLOR_BITS // 8 // self.RS_BLOCK
+    def COL_BLOCKS(self): return 0 if self.LEGACY else self.NCELLS * self.COLOR_BITS // 8 // self.RS_BLOCK
     @property
     def BLOCKS(self): return self.SYM_BLOCKS + self.COL_BLOCKS
     @property
@@ -60,7 +63,11 @@ class Geometry:
     @property
     def FRAME_SHAPE(self): return (self.IMG_H, self.IMG_W, 3)
     @property
-    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz", 66: "modebu_template.npz"}[self.MODE]
+    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz", 66: "modebu_template.npz", 4: "modeb_template.npz"}[self.MODE]
+    @property
+    def PALETTE(self):
+        """Common.cpp:21-54: getColor4 (colour_mode 1) / getColor4_old (colour_mode 0, the legacy modes)"""
+        return np.array([[0, 255, 255], [255, 255, 0], [255, 0, 255], [0, 255, 0]] if self.LEGACY else [[0, 255, 0], [0, 255, 255], [255, 255, 0], [255, 0, 255]], dtype=np.uint8)
     @property
     def FULL_MASK(self): return (1 << self.CHUNKS_PER_FRAME) - 1
 
@@ -92,6 +99,6 @@ def for_mode(mode=68):
     """Config::temp_conf(mode_val) for the modes the HIP library is built for (0 = the default, mode B)."""
     mode = 68 if mode in (0, None) else int(mode)
     if mode not in _CONF:
-        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm', 66 'Bu')")
+        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm', 66 'Bu', 4 '4C')")
     w, h, off, dx, dy, blk, par, scalar = _CONF[mode]
-    return Geometry(mode, w, h, off, dx, dy, blk, par, CHUNKS_PER_FRAME=6 * scalar)
+    return Geometry(mode, w, h, off, dx, dy, blk, par, CHUNKS_PER_FRAME=6 * scalar if scalar > 0 else -scalar, LEGACY=mode in (4, 8))

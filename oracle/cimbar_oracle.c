@@ -42,8 +42,12 @@ void co_geometry(int32_t o[10])
 
 void co_tile_hashes(uint64_t out16[16]) { memcpy(out16, TILE_HASH, sizeof TILE_HASH); }
 
-/* lib/cimb_translator/Common.cpp:21-31 getColor4 (colour_mode 1, Config.h:61-64) */
+/* lib/cimb_translator/Common.cpp:21-31 getColor4 (colour_mode 1, Config.h:61-64); legacy modes use colour_mode 0 = getColor4_old (:45-54) */
+#if CO_LEGACY
+static const uint8_t PALETTE[4][3] = {{0, 255, 255}, {255, 255, 0}, {255, 0, 255}, {0, 255, 0}};
+#else
 static const uint8_t PALETTE[4][3] = {{0, 255, 0}, {0, 255, 255}, {255, 255, 0}, {255, 0, 255}};
+#endif
 
 /* ------------------------------------------------------------------------------------------------ cell geometry */
 /* lib/cimb_translator/CellPositions.cpp:5-51 compute_linear */
@@ -940,6 +944,32 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 	uint8_t out[CO_RS_DATA];
 	uint32_t dummy_mask = 0;
 	int nblock = 0;
+#if CO_LEGACY
+	{
+		/* Decoder::do_decode_coupled, Decoder.h:121-161: one bit stream of 6-bit cells -- the symbol's 4 bits written as a 6-bit value at
+		 * 6 * stream index (its top 2 bits zero), then the colour's 2 bits over those top 2 -- and ONE Reed-Solomon pass over its 60 blocks. No
+		 * fountain header reaches the reader before the colour pass, so init_ccm is not called: the colour classifier runs with whatever
+		 * matrix the thread carries (or the von Kries one of color_correction == 1 from the constructor). */
+		static uint8_t bb[NCELLS * 6 / 8];
+		memset(bb, 0, sizeof bb);
+		for (int i = 0; i < NCELLS; ++i) {
+			uint8_t col[3];
+			cell_mean_rgb(rgb, t_positions[2 * i] + 1, t_positions[2 * i + 1] + 1, CELL - 2, CELL - 2, col);
+			const unsigned cbits = co_best_color(col[0], col[1], col[2], ccm);
+			t_colors[i] = (uint8_t)cbits;
+			const unsigned field = (cbits << 4) | t_symbols[i], pos = rev[i] * 6;
+			for (int k = 0; k < 6; ++k)
+				if (field & (0x20u >> k)) bb[(pos + k) >> 3] |= (uint8_t)(0x80u >> ((pos + k) & 7));
+		}
+		for (int b = 0; b < (int)sizeof bb / CO_RS_BLOCK; ++b, ++nblock) {
+			int r = co_rs_decode(bb + b * CO_RS_BLOCK, CO_RS_BLOCK, CO_RS_PARITY, out);
+			if (plain) { if (r > 0) memcpy(outbuf + (size_t)nblock * CO_RS_DATA, out, CO_RS_DATA); if (block_ok) block_ok[nblock] = r > 0; }
+			else aligner_block(&al, r > 0, out, &md, outbuf, good_mask ? good_mask : &dummy_mask);
+		}
+		free(crop);
+		return plain ? nblock * CO_RS_DATA : (int)al.total;
+	}
+#endif
 	for (int b = 0; b < SYM_BYTES / CO_RS_BLOCK; ++b, ++nblock) {          /* reed_solomon_stream.h:54-77 */
 		int r = co_rs_decode(symbuf + b * CO_RS_BLOCK, CO_RS_BLOCK, CO_RS_PARITY, out);
 		if (plain) { if (r > 0) memcpy(outbuf + (size_t)nblock * CO_RS_DATA, out, CO_RS_DATA); if (block_ok) block_ok[nblock] = r > 0; }

@@ -21,7 +21,8 @@ extern "C" {
 #endif
 
 /* One geometry per build of the oracle (cc -DCO_MODE=67 -> libcimbar_oracle_m67.so), Config.h:19-44 + GridConf.h:121-186:
- * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"), 66 = Conf8x8_micro ("Bu"). */
+ * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"), 66 = Conf8x8_micro ("Bu"), 4 = the legacy 4-colour mode ("4C": Conf8x8 with
+ * symbol and colour bits coupled in one Reed-Solomon stream, Decoder.h:121-161). */
 #ifndef CO_MODE
 #define CO_MODE 68
 #endif
@@ -52,8 +53,21 @@ extern "C" {
 #define CO_RS_BLOCK 168
 #define CO_RS_PARITY 33
 #define CO_CHUNKS_PER_FRAME 6
+#elif CO_MODE == 4                                                 /* Config.h:24-29: Conf8x8, 2 colour bits, legacy_mode (coupled decode, old palette), */
+#define CO_IMG_W 1024                                              /* fountain_chunks_scalar -10 -> 10 chunks of 750 bytes per frame */
+#define CO_IMG_H 1024
+#define CO_OFFSET 8
+#define CO_DIM_X 112
+#define CO_DIM_Y 112
+#define CO_RS_BLOCK 155
+#define CO_RS_PARITY 30
+#define CO_CHUNKS_PER_FRAME 10
+#define CO_LEGACY 1
 #else
-#error "CO_MODE must be 68, 67 or 66"
+#error "CO_MODE must be 68, 67, 66 or 4"
+#endif
+#ifndef CO_LEGACY
+#define CO_LEGACY 0
 #endif
 #define CO_CELLS (CO_DIM_X * CO_DIM_Y - 4 * 6 * 6)               /* 12400 | 8592 */
 #define CO_RS_DATA (CO_RS_BLOCK - CO_RS_PARITY)                  /* 125 | 143 | 135 */

@@ -99,7 +99,7 @@ def test_bad_arguments_are_refused(hip_decoder):
 
 
 def test_unsupported_modes_and_devices_fail_loudly():
-    for mode in (4, 8, 12345):   # the legacy 4/8-colour (coupled decode) configs are not on the GPU path (67 "Bm" and 66 "Bu" are: test_gpu_modes.py)
+    for mode in (8, 12345):   # the legacy 8-colour config is not on the GPU path (67 "Bm", 66 "Bu" and the legacy 4-colour mode 4 are: test_gpu_modes.py)
         with pytest.raises(D.CimbarHipError):
             D.HipDecoder(device=0, mode=mode)
     with pytest.raises(D.CimbarHipError):

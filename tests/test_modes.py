@@ -1,4 +1,4 @@
-"""The other 8x8 modes, no GPU: 67 ("Bm", Conf8x8_mini: 1024x720, 112x78 cells, RS(179,143), 12 chunks x 429 bytes; GridConf.h:168-189) and 66
+"""The other 8x8 modes, no GPU (plus the legacy 4-colour mode 4 -- Conf8x8's grid with the coupled decode of Decoder.h:121-161 and the old palette): 67 ("Bm", Conf8x8_mini: 1024x720, 112x78 cells, RS(179,143), 12 chunks x 429 bytes; GridConf.h:168-189) and 66
 ("Bu", Conf8x8_micro: 736x637, 80x69 cells, RS(168,135), 6 chunks x 540 bytes; GridConf.h:144-166). The oracle built for each geometry
 (oracle/libcimbar_oracle_m67.so / _m66.so, -DCO_MODE=..) against the reference build and against the committed golden vectors the reference
 build produced (tests/golden/mode67.json, mode66.json), plus the host-side geometry tables."""
@@ -19,10 +19,12 @@ from tests import frames as F
 HERE = os.path.dirname(os.path.abspath(__file__))
 # by hand from GridConf.h: total_cells, RS blocks (symbol + colour), chunk size = capacity(6) * (block - ecc) / block / chunks per frame
 EXPECT = {67: dict(NCELLS=8592, BLOCKS=36, SYM_BLOCKS=24, COL_BLOCKS=12, CHUNK=429, FRAME_BYTES=5148, CHUNKS_PER_FRAME=12),
-          66: dict(NCELLS=5376, BLOCKS=24, SYM_BLOCKS=16, COL_BLOCKS=8, CHUNK=540, FRAME_BYTES=3240, CHUNKS_PER_FRAME=6)}
+          66: dict(NCELLS=5376, BLOCKS=24, SYM_BLOCKS=16, COL_BLOCKS=8, CHUNK=540, FRAME_BYTES=3240, CHUNKS_PER_FRAME=6),
+          # legacy 4-colour: capacity(6) = 9300 bytes = 60 blocks of ONE stream; 60 * 125 / 10 chunks = 750
+          4: dict(NCELLS=12400, BLOCKS=60, SYM_BLOCKS=60, COL_BLOCKS=0, CHUNK=750, FRAME_BYTES=7500, CHUNKS_PER_FRAME=10)}
 
 
-@pytest.fixture(scope="module", params=[67, 66])
+@pytest.fixture(scope="module", params=[67, 66, 4])
 def MODE(request):
     return request.param
 
@@ -52,7 +54,7 @@ def test_geometry_tables(MODE):
     pyref.oracle_lib(MODE).co_cell_positions(P(xy))
     assert (xy == m.cell_positions()).all()
     with pytest.raises(ValueError):
-        geometry.for_mode(4)
+        geometry.for_mode(8)
 
 
 def test_golden_vectors_replay_on_the_oracle(MODE, synth67, FIX):
@@ -103,7 +105,8 @@ def test_extract_stage_matches_the_reference_build(ref, MODE, synth67):
     """Extractor::extract with the mode's own target size (Extractor.cpp:6-13, Deskewer.h:26-40) on a 1080p capture"""
     g = geometry.for_mode(MODE)
     payload, frames = F.clean_frames(synth67, 1, seed=21)
-    quad = {67: ((300, 150), (1600, 170), (290, 930), (1620, 915)), 66: ((400, 60), (1500, 75), (395, 1010), (1510, 1000))}[MODE]
+    quad = {67: ((300, 150), (1600, 170), (290, 930), (1620, 915)), 66: ((400, 60), (1500, 75), (395, 1010), (1510, 1000)),
+            4: ((500, 40), (1480, 70), (470, 1030), (1500, 1000))}[MODE]
     cam = np.ascontiguousarray(F.camera_frame(frames[0], quad=quad, background=20))
     h, w = cam.shape[:2]
     a, b = np.zeros(g.FRAME_SHAPE, np.uint8), np.zeros(g.FRAME_SHAPE, np.uint8)

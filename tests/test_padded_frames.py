@@ -8,7 +8,7 @@ from libcimbar_amd import framegen
 from oracle import pyref
 from tests import frames as F
 
-SIZES = {68: (1024, 1024), 67: (1024, 720), 66: (736, 637)}
+SIZES = {68: (1024, 1024), 67: (1024, 720), 66: (736, 637), 4: (1024, 1024)}
 EXTRA = [(16, 16), (10, 30), (7, 3), (64, 0), (1, 1), (0, 9), (301, 57)]
 
 
@@ -32,7 +32,7 @@ def padded_cases(mode, seed=3):
     return out
 
 
-@pytest.mark.parametrize("mode", [68, 67, 66])
+@pytest.mark.parametrize("mode", [68, 67, 66, 4])
 def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
     w, h = SIZES[mode]
     with pyref.ref_mode(mode):
@@ -50,7 +50,7 @@ def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [68, 67, 66])
+@pytest.mark.parametrize("mode", [68, 67, 66, 4])
 def test_gpu_padded_and_small_images_match_oracle(mode):
     import torch
     if not torch.cuda.is_available():
