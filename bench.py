@@ -272,8 +272,8 @@ def extras(dec, dev, stream, n, outs, steps):
     except Exception as e:
         out["ingest"] = {"error": repr(e)}
     # ---- modes 67 ("Bm", Conf8x8_mini: 1024x720 frames, 12 x 429 bytes), 66 ("Bu", Conf8x8_micro: 736x637, 6 x 540) and 4 (legacy 4-colour:
-    # mode B's grid, one coupled Reed-Solomon stream, 10 x 750): the same kernels compiled for the other configurations, each with its own context
-    for other in (67, 66, 4):
+    # mode B's grid, one coupled Reed-Solomon stream, 10 x 750; 8 = the 8-colour one, 10 x 875): the same kernels compiled for the other configurations, each with its own context
+    for other in (67, 66, 4, 8):
       try:
         from libcimbar_amd import HipDecoder, geometry
         g = geometry.for_mode(other)

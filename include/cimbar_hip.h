@@ -48,8 +48,9 @@ typedef struct cimbar_hip_ctx cimbar_hip_ctx;
 /* cimbard_configure_decode(mode) + `Decoder dec;` (cimbar_recv_js.cpp, Config::update, Config.h:19-50). Modes built: 68 ("B", Conf8x8,
  * 1024x1024, GridConf.h:121-142; 0 selects it too, Config::temp_conf's default), 67 ("Bm", Conf8x8_mini, 1024x720, GridConf.h:168-189) and
  * 66 ("Bu", Conf8x8_micro, 736x637, GridConf.h:144-166), and 4 (the legacy 4-colour mode, Config.h:24-29: mode B's grid with the coupled decode
- * of Decoder.h:121-161 -- one Reed-Solomon stream of 6-bit cells, the old palette, no header-derived colour correction). Any other value (8:
- * the legacy 8-colour mode; the 5x5 configurations) -> CIMBAR_HIP_EINVAL. `device` is a HIP device ordinal. Everywhere below "frame" means an
+ * of Decoder.h:121-161 -- one Reed-Solomon stream of 6-bit cells, the old palette, no header-derived colour correction) and 8 (the legacy
+ * 8-colour mode, Config.h:30-35: 7-bit cells, 70 blocks, 10 * 875 bytes) -- every mode Config::temp_conf knows. Any other value ->
+ * CIMBAR_HIP_EINVAL. `device` is a HIP device ordinal. Everywhere below "frame" means an
  * image_size_x x image_size_y RGB8 image of the context's mode, "12 * 625" the mode's chunks-per-frame * chunk size (12 * 429 in mode 67,
  * 6 * 540 in mode 66, 10 * 750 in mode 4; the mask has as many bits) and "60 blocks of 125" its RS layout (36 of 143; 24 of 135):
  * cimbar_hip_geometry reports the numbers. */

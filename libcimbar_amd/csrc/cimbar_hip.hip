@@ -56,6 +56,11 @@
 #include "mode.hip.inc"
 #undef CIMBAR_MODE
 #undef CIMBAR_NS
+#define CIMBAR_MODE 8
+#define CIMBAR_NS m8
+#include "mode.hip.inc"
+#undef CIMBAR_MODE
+#undef CIMBAR_NS
 
 #include "api.hip.inc"
 #include "comm.hip.inc"

@@ -87,8 +87,8 @@ class FrameSynth:
         self.template = torch.from_numpy(template.reshape(g.FRAME_SHAPE)).to(self.device)
         masks = torch.from_numpy(modeb.tile_masks()).to(self.device)                      # (16,8,8) bool
         pal = torch.from_numpy(g.PALETTE).to(self.device)                                 # (4,3)
-        # tile[colour*16 + symbol] (64,8,8,3): Common.cpp:150-171
-        self.tiles = (masks[None, :, :, :, None] * pal[:, None, None, None, :]).reshape(64, 8, 8, 3).to(torch.uint8)
+        # tile[colour*16 + symbol] (64 | 128,8,8,3): Common.cpp:150-171
+        self.tiles = (masks[None, :, :, :, None] * pal[:, None, None, None, :]).reshape(16 * pal.shape[0], 8, 8, 3).to(torch.uint8)
         self.stream_cell = torch.from_numpy(g.interleave_indices().astype(np.int64)).to(self.device)
         xy = g.cell_positions()
         self.cell_row = torch.from_numpy(((xy[:, 1] - g.OFFSET) // g.PITCH).astype(np.int64)).to(self.device)
@@ -102,8 +102,9 @@ class FrameSynth:
         blocks = rs_encode(payload.reshape(f * g.BLOCKS, g.RS_DATA), g.RS_PARITY).reshape(f, g.BLOCKS * g.RS_BLOCK).to(torch.int64)
         if g.LEGACY:
             # Encoder::encode_next_coupled (Encoder.h:131-163): the RS-encoded stream read 6 bits at a time, stream cell s = colour(2) | symbol(4)
-            bits = ((blocks[:, :, None] >> torch.arange(7, -1, -1, device=self.device)) & 1).reshape(f, g.NCELLS, 6)
-            w6 = torch.tensor([32, 16, 8, 4, 2, 1], device=self.device)
+            cb = 4 + g.COLOR_BITS                                                            # 6 | 7 bits per cell
+            bits = ((blocks[:, :, None] >> torch.arange(7, -1, -1, device=self.device)) & 1).reshape(f, g.NCELLS, cb)
+            w6 = 2 ** torch.arange(cb - 1, -1, -1, device=self.device)
             tiles_stream = (bits * w6).sum(dim=2)                                           # = colour * 16 + symbol
             out = torch.empty_like(tiles_stream)
             out[:, self.stream_cell] = tiles_stream
@@ -171,6 +172,6 @@ def inject_cell_errors(tile_idx, n_errors=99, seed=5678):
         cells = g.choice(out.shape[1], size=n_errors, replace=False)
         old = out[k, torch.from_numpy(cells).to(out.device)].cpu().numpy()
         new_sym = (old % 16 + g.integers(1, 16, size=n_errors)) % 16
-        new_col = g.integers(0, 4, size=n_errors)
+        new_col = g.integers(0, 4, size=n_errors)          # (a valid colour in every mode)
         out[k, torch.from_numpy(cells).to(out.device)] = torch.from_numpy(new_col * 16 + new_sym).to(out.device)
     return out

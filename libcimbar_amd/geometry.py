@@ -13,6 +13,7 @@ _CONF = {
     67: (1024, 720, 9, 112, 78, 179, 36, 2),
     66: (736, 637, 9, 80, 69, 168, 33, 1),
     4: (1024, 1024, 8, 112, 112, 155, 30, -10),     # Config.h:24-29: Conf8x8 + legacy_mode, fountain_chunks_scalar -10 = ten chunks per frame
+    8: (1024, 1024, 8, 112, 112, 155, 30, -10),     # Config.h:30-35: the same with 3 colour bits (8 colours)
 }
 
 
@@ -63,10 +64,12 @@ class Geometry:
     @property
     def FRAME_SHAPE(self): return (self.IMG_H, self.IMG_W, 3)
     @property
-    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz", 66: "modebu_template.npz", 4: "modeb_template.npz"}[self.MODE]
+    def TEMPLATE(self): return {68: "modeb_template.npz", 67: "modebm_template.npz", 66: "modebu_template.npz", 4: "modeb_template.npz", 8: "modeb_template.npz"}[self.MODE]
     @property
     def PALETTE(self):
-        """Common.cpp:21-54: getColor4 (colour_mode 1) / getColor4_old (colour_mode 0, the legacy modes)"""
+        """Common.cpp:21-84: getColor4 (colour_mode 1) / getColor4_old, getColor8_old (colour_mode 0, the legacy modes)"""
+        if self.LEGACY and self.COLOR_BITS == 3:
+            return np.array([[0, 255, 255], [127, 127, 255], [255, 0, 255], [255, 65, 65], [255, 159, 0], [255, 255, 0], [255, 255, 255], [0, 255, 0]], dtype=np.uint8)
         return np.array([[0, 255, 255], [255, 255, 0], [255, 0, 255], [0, 255, 0]] if self.LEGACY else [[0, 255, 0], [0, 255, 255], [255, 255, 0], [255, 0, 255]], dtype=np.uint8)
     @property
     def FULL_MASK(self): return (1 << self.CHUNKS_PER_FRAME) - 1
@@ -99,6 +102,7 @@ def for_mode(mode=68):
     """Config::temp_conf(mode_val) for the modes the HIP library is built for (0 = the default, mode B)."""
     mode = 68 if mode in (0, None) else int(mode)
     if mode not in _CONF:
-        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm', 66 'Bu', 4 '4C')")
+        raise ValueError(f"cimbar mode {mode} is not built (supported: 68 'B', 67 'Bm', 66 'Bu', 4 '4C', 8 '8C')")
     w, h, off, dx, dy, blk, par, scalar = _CONF[mode]
-    return Geometry(mode, w, h, off, dx, dy, blk, par, CHUNKS_PER_FRAME=6 * scalar if scalar > 0 else -scalar, LEGACY=mode in (4, 8))
+    return Geometry(mode, w, h, off, dx, dy, blk, par, COLOR_BITS=3 if mode == 8 else 2, CHUNKS_PER_FRAME=6 * scalar if scalar > 0 else -scalar,
+                    LEGACY=mode in (4, 8))

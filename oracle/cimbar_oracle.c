@@ -43,7 +43,9 @@ void co_geometry(int32_t o[10])
 void co_tile_hashes(uint64_t out16[16]) { memcpy(out16, TILE_HASH, sizeof TILE_HASH); }
 
 /* lib/cimb_translator/Common.cpp:21-31 getColor4 (colour_mode 1, Config.h:61-64); legacy modes use colour_mode 0 = getColor4_old (:45-54) */
-#if CO_LEGACY
+#if CO_LEGACY && CO_COLOR_BITS == 3   /* getColor8_old, Common.cpp:71-84 */
+static const uint8_t PALETTE[8][3] = {{0, 255, 255}, {127, 127, 255}, {255, 0, 255}, {255, 65, 65}, {255, 159, 0}, {255, 255, 0}, {255, 255, 255}, {0, 255, 0}};
+#elif CO_LEGACY
 static const uint8_t PALETTE[4][3] = {{0, 255, 255}, {255, 255, 0}, {255, 0, 255}, {0, 255, 0}};
 #else
 static const uint8_t PALETTE[4][3] = {{0, 255, 0}, {0, 255, 255}, {255, 255, 0}, {255, 0, 255}};
@@ -591,7 +593,7 @@ unsigned co_best_color(float r, float g, float b, const co_ccm* ccm)
 	int rel[3] = {c0 - c1, c1 - c2, c2 - c0};
 	unsigned best_fit = 0;
 	float best_distance = 1000000;
-	for (unsigned i = 0; i < 4; ++i) {
+	for (unsigned i = 0; i < (1u << CO_COLOR_BITS); ++i) {
 		int p0 = PALETTE[i][0], p1 = PALETTE[i][1], p2 = PALETTE[i][2];
 		int q[3] = {p0 - p1, p1 - p2, p2 - p0};
 		unsigned d = (unsigned)((rel[0] - q[0]) * (rel[0] - q[0]) + (rel[1] - q[1]) * (rel[1] - q[1]) + (rel[2] - q[2]) * (rel[2] - q[2]));
@@ -950,16 +952,16 @@ static int do_decode(const uint8_t* rgb, int w, int h, int preprocess, int color
 		 * 6 * stream index (its top 2 bits zero), then the colour's 2 bits over those top 2 -- and ONE Reed-Solomon pass over its 60 blocks. No
 		 * fountain header reaches the reader before the colour pass, so init_ccm is not called: the colour classifier runs with whatever
 		 * matrix the thread carries (or the von Kries one of color_correction == 1 from the constructor). */
-		static uint8_t bb[NCELLS * 6 / 8];
+		static uint8_t bb[NCELLS * CO_CELL_BITS / 8];
 		memset(bb, 0, sizeof bb);
 		for (int i = 0; i < NCELLS; ++i) {
 			uint8_t col[3];
 			cell_mean_rgb(rgb, t_positions[2 * i] + 1, t_positions[2 * i + 1] + 1, CELL - 2, CELL - 2, col);
 			const unsigned cbits = co_best_color(col[0], col[1], col[2], ccm);
 			t_colors[i] = (uint8_t)cbits;
-			const unsigned field = (cbits << 4) | t_symbols[i], pos = rev[i] * 6;
-			for (int k = 0; k < 6; ++k)
-				if (field & (0x20u >> k)) bb[(pos + k) >> 3] |= (uint8_t)(0x80u >> ((pos + k) & 7));
+			const unsigned field = (cbits << 4) | t_symbols[i], pos = rev[i] * CO_CELL_BITS;
+			for (int k = 0; k < CO_CELL_BITS; ++k)
+				if (field & ((1u << (CO_CELL_BITS - 1)) >> k)) bb[(pos + k) >> 3] |= (uint8_t)(0x80u >> ((pos + k) & 7));
 		}
 		for (int b = 0; b < (int)sizeof bb / CO_RS_BLOCK; ++b, ++nblock) {
 			int r = co_rs_decode(bb + b * CO_RS_BLOCK, CO_RS_BLOCK, CO_RS_PARITY, out);

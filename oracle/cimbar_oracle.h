@@ -21,8 +21,8 @@ extern "C" {
 #endif
 
 /* One geometry per build of the oracle (cc -DCO_MODE=67 -> libcimbar_oracle_m67.so), Config.h:19-44 + GridConf.h:121-186:
- * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"), 66 = Conf8x8_micro ("Bu"), 4 = the legacy 4-colour mode ("4C": Conf8x8 with
- * symbol and colour bits coupled in one Reed-Solomon stream, Decoder.h:121-161). */
+ * 68 = Conf8x8 ("B", the default), 67 = Conf8x8_mini ("Bm"), 66 = Conf8x8_micro ("Bu"), 4 / 8 = the legacy 4- and 8-colour modes ("4C" / "8C": Conf8x8
+ * with symbol and colour bits coupled in one Reed-Solomon stream, Decoder.h:121-161). */
 #ifndef CO_MODE
 #define CO_MODE 68
 #endif
@@ -63,15 +63,30 @@ extern "C" {
 #define CO_RS_PARITY 30
 #define CO_CHUNKS_PER_FRAME 10
 #define CO_LEGACY 1
+#elif CO_MODE == 8                                                 /* Config.h:30-35: the legacy 8-colour mode: 3 colour bits, 7-bit cells, 70 blocks, */
+#define CO_IMG_W 1024                                              /* ten chunks of 875 bytes */
+#define CO_IMG_H 1024
+#define CO_OFFSET 8
+#define CO_DIM_X 112
+#define CO_DIM_Y 112
+#define CO_RS_BLOCK 155
+#define CO_RS_PARITY 30
+#define CO_CHUNKS_PER_FRAME 10
+#define CO_LEGACY 1
+#define CO_COLOR_BITS 3
 #else
-#error "CO_MODE must be 68, 67, 66 or 4"
+#error "CO_MODE must be 68, 67, 66, 4 or 8"
 #endif
 #ifndef CO_LEGACY
 #define CO_LEGACY 0
 #endif
+#ifndef CO_COLOR_BITS
+#define CO_COLOR_BITS 2
+#endif
+#define CO_CELL_BITS (4 + CO_COLOR_BITS)
 #define CO_CELLS (CO_DIM_X * CO_DIM_Y - 4 * 6 * 6)               /* 12400 | 8592 */
 #define CO_RS_DATA (CO_RS_BLOCK - CO_RS_PARITY)                  /* 125 | 143 | 135 */
-#define CO_CHUNK (CO_CELLS * 6 / 8 / CO_RS_BLOCK * CO_RS_DATA / CO_CHUNKS_PER_FRAME)   /* 625 | 429 */
+#define CO_CHUNK (CO_CELLS * CO_CELL_BITS / 8 / CO_RS_BLOCK * CO_RS_DATA / CO_CHUNKS_PER_FRAME)   /* 625 | 429 | 540 | 750 | 875 */
 
 /* the constants above, for the tests: {mode, image w, image h, cells, chunk bytes, RS block, RS parity, cells per row, cell rows, cell offset} */
 void co_geometry(int32_t out10[10]);

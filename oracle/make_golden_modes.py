@@ -17,7 +17,7 @@ from libcimbar_amd import framegen  # noqa: E402
 from oracle import pyref  # noqa: E402
 from tests import frames as F  # noqa: E402
 
-MODES = (67, 66, 4)
+MODES = (67, 66, 4, 8)
 
 
 def cases(synth):

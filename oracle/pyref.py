@@ -28,7 +28,7 @@ _ref = None
 # mode -> (image w, image h, cells, chunk bytes, RS blocks per frame, RS data bytes per block, chunks per frame): Config.h:101-165 for the modes
 # the oracle is built for
 GEOMETRY = {68: (1024, 1024, 12400, 625, 60, 125, 12), 67: (1024, 720, 8592, 429, 36, 143, 12), 66: (736, 637, 5376, 540, 24, 135, 6),
-            4: (1024, 1024, 12400, 750, 60, 125, 10)}
+            4: (1024, 1024, 12400, 750, 60, 125, 10), 8: (1024, 1024, 12400, 875, 70, 125, 10)}
 
 
 def oracle_so(mode=68):

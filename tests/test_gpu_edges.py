@@ -99,7 +99,7 @@ def test_bad_arguments_are_refused(hip_decoder):
 
 
 def test_unsupported_modes_and_devices_fail_loudly():
-    for mode in (8, 12345):   # the legacy 8-colour config is not on the GPU path (67 "Bm", 66 "Bu" and the legacy 4-colour mode 4 are: test_gpu_modes.py)
+    for mode in (5, 12345):   # (every mode of Config::temp_conf is built: 68, 67, 66, 4, 8 -- test_gpu_modes.py)
         with pytest.raises(D.CimbarHipError):
             D.HipDecoder(device=0, mode=mode)
     with pytest.raises(D.CimbarHipError):

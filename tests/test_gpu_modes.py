@@ -17,7 +17,7 @@ from tests import frames as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[67, 66, 4])
+@pytest.fixture(scope="module", params=[67, 66, 4, 8])
 def MODE(request):
     return request.param
 
@@ -77,7 +77,8 @@ def check(dec, frames, pre=0, cc=2, names=None):
 def test_geometry_reported_by_the_library(dec67, MODE):
     g = dec67.geo
     assert (g.MODE, g.IMG_W, g.IMG_H, g.NCELLS, g.CHUNK, g.BLOCKS, g.RS_BLOCK, g.RS_PARITY) == \
-        {67: (67, 1024, 720, 8592, 429, 36, 179, 36), 66: (66, 736, 637, 5376, 540, 24, 168, 33), 4: (4, 1024, 1024, 12400, 750, 60, 155, 30)}[MODE]
+        {67: (67, 1024, 720, 8592, 429, 36, 179, 36), 66: (66, 736, 637, 5376, 540, 24, 168, 33), 4: (4, 1024, 1024, 12400, 750, 60, 155, 30),
+         8: (8, 1024, 1024, 12400, 875, 70, 155, 30)}[MODE]
     o = (ctypes.c_int32 * 10)()
     pyref.oracle_lib(MODE).co_geometry(o)
     assert list(o) == [MODE, g.IMG_W, g.IMG_H, g.NCELLS, g.CHUNK, g.RS_BLOCK, g.RS_PARITY, g.DIM_X, g.DIM_Y, g.OFFSET]
@@ -177,7 +178,7 @@ def test_other_sizes_and_both_modes_coexist(dec67, synth67, hip_decoder, synth, 
         _, cm, mm = dec67.decode_frame(fm[k])
         assert mb == 0xFFF and mm == GEO.FULL_MASK and (cb.reshape(-1) == pb[k]).all() and (cm.reshape(-1) == pm[k]).all()
     with pytest.raises(D.CimbarHipError):
-        D.HipDecoder(0, 8)           # the legacy 8-colour mode is not built
+        D.HipDecoder(0, 5)           # not a mode of Config::temp_conf
 
 
 def test_camera_captures_scan_extract_decode(dec67, synth67, MODE, GEO):
@@ -185,7 +186,8 @@ def test_camera_captures_scan_extract_decode(dec67, synth67, MODE, GEO):
     oracle's co_extract + co_decode_fountain built for the same mode"""
     quads = {67: [((300, 150), (1600, 170), (290, 930), (1620, 915)), ((250, 100), (1700, 100), (250, 1000), (1700, 1000)), ((420, 200), (1500, 230), (400, 900), (1480, 880))],
              66: [((400, 60), (1500, 75), (395, 1010), (1510, 1000)), ((380, 40), (1540, 40), (380, 1044), (1540, 1044)), ((500, 120), (1420, 140), (480, 930), (1400, 905))],
-             4: [((500, 40), (1480, 70), (470, 1030), (1500, 1000)), ((448, 28), (1472, 28), (448, 1052), (1472, 1052)), ((520, 60), (1450, 40), (540, 1010), (1430, 1040))]}[MODE]
+             4: [((500, 40), (1480, 70), (470, 1030), (1500, 1000)), ((448, 28), (1472, 28), (448, 1052), (1472, 1052)), ((520, 60), (1450, 40), (540, 1010), (1430, 1040))]}
+    quads = quads[4 if MODE == 8 else MODE]
     payload, frames = F.clean_frames(synth67, len(quads), seed=44)
     cams = np.ascontiguousarray(np.stack([F.camera_frame(frames[k], quad=q, background=bg, blur=bl) for k, (q, bg, bl) in enumerate(zip(quads, (0, 40, 255), (0.0, 0.6, 0.0)))]))
     O = pyref.oracle_lib(MODE)

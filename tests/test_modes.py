@@ -21,10 +21,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EXPECT = {67: dict(NCELLS=8592, BLOCKS=36, SYM_BLOCKS=24, COL_BLOCKS=12, CHUNK=429, FRAME_BYTES=5148, CHUNKS_PER_FRAME=12),
           66: dict(NCELLS=5376, BLOCKS=24, SYM_BLOCKS=16, COL_BLOCKS=8, CHUNK=540, FRAME_BYTES=3240, CHUNKS_PER_FRAME=6),
           # legacy 4-colour: capacity(6) = 9300 bytes = 60 blocks of ONE stream; 60 * 125 / 10 chunks = 750
-          4: dict(NCELLS=12400, BLOCKS=60, SYM_BLOCKS=60, COL_BLOCKS=0, CHUNK=750, FRAME_BYTES=7500, CHUNKS_PER_FRAME=10)}
+          4: dict(NCELLS=12400, BLOCKS=60, SYM_BLOCKS=60, COL_BLOCKS=0, CHUNK=750, FRAME_BYTES=7500, CHUNKS_PER_FRAME=10),
+          # legacy 8-colour: capacity(7) = 10850 bytes = 70 blocks; 70 * 125 / 10 = 875
+          8: dict(NCELLS=12400, BLOCKS=70, SYM_BLOCKS=70, COL_BLOCKS=0, CHUNK=875, FRAME_BYTES=8750, CHUNKS_PER_FRAME=10)}
 
 
-@pytest.fixture(scope="module", params=[67, 66, 4])
+@pytest.fixture(scope="module", params=[67, 66, 4, 8])
 def MODE(request):
     return request.param
 
@@ -54,7 +56,7 @@ def test_geometry_tables(MODE):
     pyref.oracle_lib(MODE).co_cell_positions(P(xy))
     assert (xy == m.cell_positions()).all()
     with pytest.raises(ValueError):
-        geometry.for_mode(8)
+        geometry.for_mode(5)
 
 
 def test_golden_vectors_replay_on_the_oracle(MODE, synth67, FIX):
@@ -106,7 +108,7 @@ def test_extract_stage_matches_the_reference_build(ref, MODE, synth67):
     g = geometry.for_mode(MODE)
     payload, frames = F.clean_frames(synth67, 1, seed=21)
     quad = {67: ((300, 150), (1600, 170), (290, 930), (1620, 915)), 66: ((400, 60), (1500, 75), (395, 1010), (1510, 1000)),
-            4: ((500, 40), (1480, 70), (470, 1030), (1500, 1000))}[MODE]
+            4: ((500, 40), (1480, 70), (470, 1030), (1500, 1000)), 8: ((500, 40), (1480, 70), (470, 1030), (1500, 1000))}[MODE]
     cam = np.ascontiguousarray(F.camera_frame(frames[0], quad=quad, background=20))
     h, w = cam.shape[:2]
     a, b = np.zeros(g.FRAME_SHAPE, np.uint8), np.zeros(g.FRAME_SHAPE, np.uint8)

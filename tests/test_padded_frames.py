@@ -8,7 +8,7 @@ from libcimbar_amd import framegen
 from oracle import pyref
 from tests import frames as F
 
-SIZES = {68: (1024, 1024), 67: (1024, 720), 66: (736, 637), 4: (1024, 1024)}
+SIZES = {68: (1024, 1024), 67: (1024, 720), 66: (736, 637), 4: (1024, 1024), 8: (1024, 1024)}
 EXTRA = [(16, 16), (10, 30), (7, 3), (64, 0), (1, 1), (0, 9), (301, 57)]
 
 
