@@ -352,7 +352,7 @@ def main():
     NB = max(D, 2)
     # R distinct input batches, decoded in rotation: steps in flight at the same time never read the same frames (two threshold passes
     # walking the same addresses a few frames apart would share lines through L2 / the Infinity Cache, which a real stream cannot)
-    R = max(dec.pipeline_depth, 2)
+    R = max(dec.pipeline_depth, 4)          # (12 GB per rotation: nothing survives in the 256 MiB Infinity Cache from one use to the next)
     batches = [make_frames(n, dev, seed=1234 + 97 * rank + 7919 * b, dec=dec, check=(b == 0)) for b in range(R)]
     payloads = [p for p, _ in batches]
     inputs = [f for _, f in batches]
