@@ -74,6 +74,19 @@ def measured_traffic(kernel, n):
         return None, None
 
 
+def usable_cpus():
+    """CPUs this process may really use: the scheduler affinity, cut down to the container's CPU quota where there is one (cgroup v2 cpu.max).
+    The GPU boxes of the pool report 256 hardware threads and run under a 16-CPU quota: threads beyond the quota only get throttled."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
     """Time the CPU decoder on host cores over a bounded sample of the same frames, and compare what it decodes with the
     GPU's chunks for those frames (SHA-256 over the sample's 12 x 625-byte chunk slots, frame order)."""
@@ -82,7 +95,8 @@ def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
     ref = pyref.ref_lib()
     kind = "reference" if ref is not None else "port"
     orc = pyref.oracle_lib()
-    ncores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
+    ncores = usable_cpus()
     threads = max(1, min(ncores, 64, len(frames_host)))
 
     def decode_one(fr, state, chunks=None):
@@ -123,9 +137,10 @@ def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": ncores, "threads": threads, "kind": kind,
+    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": ncores, "threads": threads, "host_hw_threads": hw, "kind": kind,
             "sample": f"{sum(done)} clean mode-B 1024x1024 frames from the bench batch ({len(frames_host)} distinct), {threads} threads x 1 "
-                      f"decoder each on a {ncores}-core host, {dt:.1f} s wall, single-thread {1.0 / per_frame:.1f} frames/s",
+                      f"decoder each on the {ncores} CPUs this process may use (host: {hw} hardware threads), {dt:.1f} s wall, "
+                      f"single-thread {1.0 / per_frame:.1f} frames/s",
             "payload_sha_match": sha_cpu == sha_gpu, "payload_sha256": sha_cpu}
 
 

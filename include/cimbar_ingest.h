@@ -34,7 +34,7 @@ typedef struct cimbar_ingest cimbar_ingest;
  * (e.g. the fountain sink is complete). */
 typedef int (*cimbar_ingest_sink_fn)(void* user, const uint8_t* chunks, const uint32_t* masks, int first_frame, int n);
 
-/* threads: PNG decode threads (<= 0: one per hardware thread, at most 64); batch_frames: frames per device batch (<= 0: 64);
+/* threads: PNG decode threads (<= 0: one per CPU the process may use -- hardware threads or the cgroup CPU quota, whichever is smaller -- at most 128); batch_frames: frames per device batch (<= 0: 64);
  * ring: batches in flight between the host pool and the device (2..4, <= 0: 3) */
 int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out);
 void cimbar_ingest_destroy(cimbar_ingest* ing);
