@@ -161,3 +161,58 @@ def test_split_batch_floods_with_spilling_heaps(synth):
     torch.cuda.synchronize()
     assert int(dec.tap(D.TAP_FLOOD, n).sum()) == n
     assert bool((masks == 0xFFF).all()) and bool((chunks == payload).all())
+
+
+@pytest.mark.parametrize("mode", [68, 67, 66])
+def test_certified_batch_flood_fuzz_against_exact_replay(mode):
+    """256 randomly distorted frames per mode (shifts, wipes, noise, tears between two shifts, random 9x9 patches): wherever the batch-parallel
+    flood certifies a frame, its symbols and drift equal the exact replay's -- the soundness claim of k_flood_wave, on the kernel itself"""
+    import os
+    import torch
+    from libcimbar_amd import HipDecoder, framegen
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    synth = framegen.FrameSynth("cpu", mode)
+    payload, fr = F.clean_frames(synth, 8, seed=500 + mode)
+    h, w = fr.shape[1:3]
+    g = np.random.default_rng(mode)
+    frames = []
+    for k in range(256):
+        f = F.shift(fr[k % 8], int(g.integers(-3, 4)), int(g.integers(-3, 4)))
+        kind = k % 6
+        if kind == 1:
+            y0, x0 = int(g.integers(0, h - 100)), int(g.integers(0, w - 100))
+            f = F.blank_region(f, y0, y0 + int(g.integers(20, 300)), x0, x0 + int(g.integers(20, 300)), value=int(g.integers(0, 256)))
+        elif kind == 2:
+            f = F.add_noise(f, int(g.integers(3, 40)), k)
+        elif kind == 3:
+            cut = int(g.integers(100, h - 100))
+            f = np.concatenate([F.shift(fr[k % 8], 1, 0)[:cut], F.shift(fr[k % 8], 0, 1)[cut:]], 0)     # a tear: two different shifts
+        elif kind == 4:
+            f = f.copy()
+            for _ in range(int(g.integers(1, 40))):
+                y, x = int(g.integers(8, h - 20)), int(g.integers(8, w - 20))
+                f[y:y + 9, x:x + 9] = g.integers(0, 256, (9, 9, 3))
+        elif kind == 5:
+            f = F.shift(fr[k % 8], int(g.integers(-7, 8)), int(g.integers(-7, 8)))                       # up to the drift limit
+        frames.append(f)
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    outs = []
+    for wave in ("1", "0"):
+        os.environ["CIMBAR_HIP_FLOOD_WAVE"] = wave
+        try:
+            dec = HipDecoder(0, mode)
+        finally:
+            os.environ.pop("CIMBAR_HIP_FLOOD_WAVE", None)
+        total, chunks, masks = dec.decode_batch(frames)
+        outs.append((chunks.copy(), masks.copy(), dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_FLOOD_PATH, n)))
+        dec.close()
+    a, b = outs
+    assert (b[4] <= 1).all() and ((a[4] != 0) == (b[4] != 0)).all()
+    for k in range(n):
+        assert (a[2][k] == b[2][k]).all(), f"mode {mode} frame {k} (path {a[4][k]}): symbols differ"
+        if a[4][k]:
+            assert (a[3][k] == b[3][k]).all(), f"mode {mode} frame {k} (path {a[4][k]}): drift differs"
+        assert a[1][k] == b[1][k] and (a[0][k] == b[0][k]).all(), k
+    assert (a[4] == 2).sum() >= 40, f"too few frames certified: {np.bincount(a[4])}"
