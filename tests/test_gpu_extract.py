@@ -178,6 +178,16 @@ def test_scan_extract_decode_chain_equals_the_reference_chain(hip_decoder, synth
         assert masks[k] == wmask and (chunks[k] == wchunks).all(), k
         want_total += r
     assert total == want_total
+    # the caller's explicit choice (cimbar.cpp:186-190, --preprocess 0 | 1) overrides the extractor's verdict for every capture
+    for pre in (0, 1):
+        hip_decoder.reset_ccm()
+        total, chunks, masks, status = hip_decoder.scan_extract_decode_batch(cams, preprocess=pre)
+        ref.ref_reset_ccm()
+        for k in range(n):
+            ext = np.zeros((1024, 1024, 3), np.uint8)
+            assert ref.ref_extract(P(cams[k]), w, h, P(ext)) == status[k]
+            r, wchunks, wmask = pyref.ref_decode(ext, pre, 2, 0)
+            assert masks[k] == wmask and (chunks[k] == wchunks).all(), (pre, k)
 
 
 def test_extract_of_a_capture_that_needs_the_9x9_blur(hip_decoder, synth, oracle):
