@@ -209,7 +209,10 @@ enum {
 	CIMBAR_HIP_TAP_RS_OK = 4,      /* n * 60 bytes    : 1 = libcorrect-equivalent decode returned > 0, per RS block */
 	CIMBAR_HIP_TAP_FLOOD = 5,      /* n bytes         : 1 = frame needed the exact flood-order pass */
 	CIMBAR_HIP_TAP_CCM = 6,        /* n * 10 floats   : 3x3 matrix used for the colour pass + active flag */
-	CIMBAR_HIP_TAP_FLOOD_PATH = 7  /* n bytes         : 0 = parallel pass was exact, 1 = exact flood replay, 2 = certified batch flood */
+	CIMBAR_HIP_TAP_FLOOD_PATH = 7, /* n bytes         : 0 = parallel pass was exact, 1 = exact flood replay, 2 = certified batch flood */
+	CIMBAR_HIP_TAP_FLOOD_INFO = 8  /* n u32           : what the batch-parallel flood made of a flagged frame: low byte 0 = certified, 1..4 = the rule
+	                                  that declined it, 5 = out of super-rounds; bits 8..15 the super-round; bits 16.. cells decoded by then.
+	                                  0xFFFFFFFF for frames that were never flagged */
 };
 int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes);
 

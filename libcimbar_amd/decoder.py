@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM, TAP_FLOOD_PATH = range(8)
+TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM, TAP_FLOOD_PATH, TAP_FLOOD_INFO = range(9)
 
 # every symbol include/cimbar_hip.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
 EXPORTS = (
@@ -369,7 +369,7 @@ class HipDecoder:
         shapes = {
             TAP_BITPLANE: ((n, self.geo.IMG_W * self.geo.IMG_H // 8), np.uint8), TAP_SYMBOLS: ((n, self.geo.NCELLS), np.uint8),
             TAP_COLORS: ((n, self.geo.NCELLS), np.uint8), TAP_DRIFT: ((n, self.geo.NCELLS, 2), np.int8),
-            TAP_RS_OK: ((n, self.geo.BLOCKS), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8),
+            TAP_RS_OK: ((n, self.geo.BLOCKS), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8), TAP_FLOOD_INFO: ((n,), np.uint32),
         }
         shape, dt = shapes[what]
         out = np.zeros(shape, dtype=dt)

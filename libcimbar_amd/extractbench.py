@@ -83,9 +83,16 @@ def run(dec, dev, stream, synth, n=256, reps=3):
     full = (m == 0xFFF)
     payload_ok = bool((chunks[torch.from_numpy(full).to(dev)] == payload[torch.from_numpy(full).to(dev)]).all().item())
     path = dec.tap(7, n)
+    info = dec.tap(8, n)                      # what the batch-parallel flood made of each flagged frame
+    seen = info[info != 0xFFFFFFFF]
+    rules = {str(int(r)): int(((seen & 0xFF) == r).sum()) for r in np.unique(seen & 0xFF)}
+    declined = seen[(seen & 0xFF) != 0]
     return {"config5_extract": {
         "captures": n, "size": [w, h], "ms": round(best_all * 1e3, 3), "captures_per_s": round(n / best_all, 1),
         "extract_only_ms": round(best_ext * 1e3, 3), "extract_only_captures_per_s": round(n / best_ext, 1),
         "extracted": int((st > 0).sum()), "needs_sharpen": int((st == 2).sum()), "frames_fully_decoded": int(full.sum()),
         "payload_ok_where_decoded": payload_ok, "flood_exact_frames": int((path == 1).sum()), "flood_batch_frames": int((path == 2).sum()),
+        "flood_wave_outcome_by_rule": rules,
+        "flood_wave_declined_at": {"median_super_round": int(np.median((declined >> 8) & 0xFF)) if declined.size else None,
+                                   "median_cells_decoded": int(np.median(declined >> 16)) if declined.size else None},
         "note": "device-resident 1080p captures -> cimbar_hip_scan_extract_decode_batch (blur, Otsu, anchor search, warp, decode), preprocess = guess"}}
