@@ -200,6 +200,37 @@ void cimbar_hip_comm_destroy(cimbar_hip_comm* comm);
 int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int root, const uint8_t* chunks, const uint32_t* masks, int n,
                              uint8_t* all_chunks, uint32_t* all_masks, void* hip_stream);
 
+/* ---- PNG decode on the device (what cv::imread does in front of the decoder, cimbar.cpp:132-133) --------------------
+ * A batch of PNG images whose zlib streams (the concatenated IDAT payloads) already sit in device memory -> dense RGB8 frames in device
+ * memory, without the decoded pixels ever crossing PCIe: inflate (one wavefront per image, Huffman decode + LZ77 window in LDS, Adler-32
+ * checked) and the scanline un-filter (rows skewed over the lanes). 8 bits per sample, non-interlaced, colour types 0 (gray, replicated),
+ * 2 (RGB), 3 (palette), 6 (RGBA, alpha dropped) -- what cv::imread(IMREAD_COLOR) + BGR2RGB gives. Context-free: `device` is a HIP ordinal.
+ *   d_zbuf / zbuf_bytes : the streams (and palettes), device memory
+ *   d_desc              : n descriptors, device memory
+ *   d_scratch           : n * scratch_stride bytes for the filtered scanlines; scratch_stride >= cimbar_hip_png_scratch_bytes(), multiple of 16
+ *   d_rgb               : n * rgb_stride bytes; image i's width*height*3 bytes start at i * rgb_stride
+ *   d_status            : n words: 0 or a CIMBAR_HIP_PNG_E* code per image (a refused image leaves its rgb slot undefined)
+ * Enqueued on hip_stream; returns 0, or a negative code if the launch itself failed. libcimbar_ingest.so's device mode
+ * (include/cimbar_ingest.h) is the host side that parses the files and fills these buffers. */
+enum {
+	CIMBAR_HIP_PNG_EHEADER = -30,   /* descriptor / zlib header not acceptable (colour type, size, window, preset dictionary, alignment) */
+	CIMBAR_HIP_PNG_ESTREAM = -31,   /* invalid deflate stream (block type, stored length, distance too far back, invalid code, truncated, filter type) */
+	CIMBAR_HIP_PNG_ECODES = -32,    /* over-subscribed or incomplete Huffman code set (zlib's inflate_table rules) */
+	CIMBAR_HIP_PNG_ESIZE = -33,     /* the stream inflates to more or fewer bytes than height * (1 + width * bytes per pixel), or the slot is too small */
+	CIMBAR_HIP_PNG_ECHECK = -34     /* Adler-32 mismatch */
+};
+typedef struct cimbar_hip_png_desc {
+	uint64_t zoff;        /* byte offset of the image's zlib stream in d_zbuf, a multiple of 16 */
+	uint32_t zlen;        /* its length */
+	uint32_t width, height;
+	uint32_t color_type;  /* 0, 2, 3, 6 */
+	uint32_t pal_off;     /* colour type 3: byte offset in d_zbuf of 256 RGB palette entries (768 bytes) */
+	uint32_t reserved;
+} cimbar_hip_png_desc;
+size_t cimbar_hip_png_scratch_bytes(unsigned width, unsigned height, unsigned color_type);
+int cimbar_hip_png_decode_batch(int device, const uint8_t* d_zbuf, size_t zbuf_bytes, const cimbar_hip_png_desc* d_desc, int n, uint8_t* d_scratch,
+                                size_t scratch_stride, uint8_t* d_rgb, size_t rgb_stride, int32_t* d_status, void* hip_stream);
+
 /* ---- stage taps (parity tests / profiling; all buffers host memory, sized for the LAST decoded batch of n frames) --- */
 enum {
 	CIMBAR_HIP_TAP_BITPLANE = 0,   /* n * 131072 bytes: CimbReader::_grayscale layout (bit x+1024*y, MSB first) */

@@ -37,6 +37,22 @@ typedef int (*cimbar_ingest_sink_fn)(void* user, const uint8_t* chunks, const ui
 /* threads: PNG decode threads (<= 0: one per CPU the process may use -- hardware threads or the cgroup CPU quota, whichever is smaller -- at most 128); batch_frames: frames per device batch (<= 0: 64);
  * ring: batches in flight between the host pool and the device (2..4, <= 0: 3) */
 int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out);
+
+/* Where cimbar_ingest_run_files decodes the PNGs.
+ *   CIMBAR_INGEST_PNG_HOST   : on the host pool (zlib inflate + un-filter per thread), decoded frames cross PCIe -- cimbar_ingest_create.
+ *   CIMBAR_INGEST_PNG_DEVICE : the host threads only read the files and copy their IDAT payloads into the pinned batch; the compressed bytes
+ *       cross PCIe and cimbar_hip_png_decode_batch (include/cimbar_hip.h) inflates and un-filters them on the device, straight into the
+ *       frames the decoder reads. Takes what cv::imwrite / any ordinary tool writes (8 bits per sample, gray / RGB / RGBA / palette, not
+ *       interlaced); a file outside that, or whose stream the device refuses (invalid deflate data, Adler-32 mismatch), is skipped like an
+ *       unreadable one. There is no host fallback inside this mode. batch_frames <= 0: 512 (the inflate pass runs one wavefront per image:
+ *       large batches are what fills the GPU); zbytes_per_frame: pinned + device room for a frame's compressed stream (0: a quarter of the
+ *       decoded frame; a batch whose streams together exceed batch_frames * zbytes_per_frame loses the files that no longer fit).
+ *       cimbar_ingest_run_raw is not available on such an ingest. */
+enum { CIMBAR_INGEST_PNG_HOST = 0, CIMBAR_INGEST_PNG_DEVICE = 1 };
+int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, int png_mode, size_t zbytes_per_frame, cimbar_ingest** out);
+/* device PNG mode, last cimbar_ingest_run_files: [0] files seen, [1] refused by the host's chunk walk (or unreadable / wrong size / no room),
+ * [2] refused by the device, [3] bytes copied to the device */
+int cimbar_ingest_png_stats(const cimbar_ingest* ing, int64_t out4[4]);
 void cimbar_ingest_destroy(cimbar_ingest* ing);
 const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
 

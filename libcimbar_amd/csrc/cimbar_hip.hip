@@ -64,3 +64,4 @@
 
 #include "api.hip.inc"
 #include "comm.hip.inc"
+#include "png.hip.inc"

@@ -7,12 +7,19 @@
 // The batch being filled, the batch being copied and the batches being decoded are different ring slots, so PNG decoding, PCIe traffic and
 // the kernels overlap; the calling thread only issues work and hands finished batches to the callback. It replaces cv::imread + cvtColor of
 // ./cimbar's loop (/root/reference/src/exe/cimbar/cimbar.cpp:124-162), which decodes one file at a time on one thread.
+//
+// Device PNG mode (cimbar_ingest_create_ex(..., CIMBAR_INGEST_PNG_DEVICE)): the host threads only read the files and copy their IDAT payloads
+// into the pinned batch; the compressed bytes cross PCIe (a tenth of the decoded frames) and cimbar_hip_png_decode_batch inflates and
+// un-filters them on the device, one stream per ring slot so that the inflate passes of consecutive batches overlap:
+//   files --[pool: read + chunk walk + memcpy of the IDAT bytes]--> pinned zlib streams + descriptors --[copy stream]--> device
+//        --[slot stream: k_png_inflate, k_png_unfilter]--> device frames --[context streams: decode]--> chunks, masks, PNG status --> sink
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -126,6 +133,37 @@ int png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t cap, unsigne
 	return 0;
 }
 
+// device PNG mode: walk the chunks, return the geometry and where the IDAT payloads are; nothing is decompressed on the host.
+// Only what the device kernels take (8 bits per sample, non-interlaced, colour type 0 / 2 / 3 / 6) is accepted.
+struct PngInfo { unsigned w = 0, h = 0, ctype = 0; size_t zlen = 0; const uint8_t* plte = nullptr; unsigned npal = 0; std::vector<std::pair<const uint8_t*, uint32_t>> idat; };
+int png_walk(const uint8_t* png, size_t len, PngInfo& info)
+{
+	static const uint8_t SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	if (len < 8 + 25 || std::memcmp(png, SIG, 8) != 0) return CIMBAR_INGEST_EFORMAT;
+	size_t pos = 8;
+	unsigned depth = 0, interlace = 0;
+	bool have_ihdr = false;
+	info.idat.clear(); info.zlen = 0; info.plte = nullptr; info.npal = 0;
+	while (pos + 12 <= len) {
+		const uint32_t clen = be32(png + pos);
+		const uint8_t* tag = png + pos + 4;
+		const uint8_t* data = png + pos + 8;
+		if ((size_t)clen > len - pos - 12) return CIMBAR_INGEST_EFORMAT;
+		if (!std::memcmp(tag, "IHDR", 4)) {
+			if (clen != 13) return CIMBAR_INGEST_EFORMAT;
+			info.w = be32(data); info.h = be32(data + 4); depth = data[8]; info.ctype = data[9]; interlace = data[12];
+			have_ihdr = true;
+		} else if (!std::memcmp(tag, "PLTE", 4)) { info.plte = data; info.npal = clen / 3 > 256 ? 256 : clen / 3; }
+		else if (!std::memcmp(tag, "IDAT", 4)) { if (clen) info.idat.emplace_back(data, clen); info.zlen += clen; }
+		else if (!std::memcmp(tag, "IEND", 4)) break;
+		pos += 12 + (size_t)clen;
+	}
+	if (!have_ihdr || info.w == 0 || info.h == 0 || depth != 8 || interlace != 0) return CIMBAR_INGEST_EFORMAT;
+	if (!(info.ctype == 0 || info.ctype == 2 || info.ctype == 3 || info.ctype == 6) || info.zlen < 6 || info.zlen > 0xFFFFFFF0u) return CIMBAR_INGEST_EFORMAT;
+	if (info.ctype == 3 && !info.plte) return CIMBAR_INGEST_EFORMAT;
+	return 0;
+}
+
 bool read_file(const char* path, std::vector<uint8_t>& out)
 {
 	FILE* f = std::fopen(path, "rb");
@@ -158,10 +196,21 @@ struct cimbar_ingest {
 		uint32_t* h_masks = nullptr; uint32_t* d_masks = nullptr;
 		hipEvent_t done = nullptr;
 		std::vector<uint8_t> valid;
+		// device PNG mode
+		uint8_t* h_z = nullptr; uint8_t* d_z = nullptr;                       // zlib streams (+ palettes) of the batch, 16-byte aligned pieces
+		cimbar_hip_png_desc* h_desc = nullptr; cimbar_hip_png_desc* d_desc = nullptr;
+		uint8_t* d_scratch = nullptr;                                           // filtered scanlines between the two PNG kernels
+		int32_t* h_status = nullptr; int32_t* d_status = nullptr;
+		hipStream_t png_stream = nullptr;
+		hipEvent_t copied = nullptr;
 	};
+	int png_mode = CIMBAR_INGEST_PNG_HOST;
+	size_t zcap = 0;                  // bytes of h_z / d_z per slot
+	size_t scratch_stride = 0;
 	std::vector<Slot> slots;
 	hipStream_t copy_stream = nullptr, out_stream = nullptr;
 	double t_wall = 0, t_host = 0, t_wait = 0;
+	int64_t png_files = 0, png_refused_host = 0, png_refused_device = 0, png_bytes = 0;   // device PNG mode, last run
 };
 
 namespace {
@@ -175,7 +224,8 @@ namespace {
 		}                                                                                \
 	} while (0)
 
-// fill(i, dst) produces frame i into dst (pinned memory) and says whether it is a usable frame
+// fill(i, slot, j, zcursor) produces frame i as entry j of the slot's batch (host mode: RGB8 into the pinned frames; device PNG mode: the
+// file's zlib stream + descriptor, the space taken from the batch's cursor) and says whether it is a usable frame
 // direct != nullptr: the frames already sit in page-locked host memory (hipHostMalloc / hipHostRegister) -- no staging threads, the H2D
 // copies read the caller's buffer
 template <typename FILL>
@@ -184,6 +234,10 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 	if (n <= 0) return 0;
 	ICHK(hipSetDevice(ing->device));
 	const int B = ing->B, R = ing->R, nbatch = (n + B - 1) / B;
+	const bool dev_png = ing->png_mode == CIMBAR_INGEST_PNG_DEVICE;
+	std::unique_ptr<std::atomic<size_t>[]> zcur(new std::atomic<size_t>[(size_t)nbatch]);
+	for (int k = 0; k < nbatch; ++k) zcur[(size_t)k].store(0);
+	ing->png_files = ing->png_refused_host = ing->png_refused_device = ing->png_bytes = 0;
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<int> filled((size_t)nbatch, 0);      // frames of batch k staged so far
@@ -204,7 +258,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			}
 			if (stop.load()) break;
 			const double t0 = now_s();
-			const bool ok = fill(i, ing->slots[s].h_in + (size_t)(i - k * B) * ing->frame);
+			const bool ok = fill(i, ing->slots[s], i - k * B, zcur[(size_t)k]);
 			ing->slots[s].valid[(size_t)(i - k * B)] = ok ? 1 : 0;
 			mine += now_s() - t0;
 			{
@@ -236,6 +290,11 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 		wait_s += now_s() - t0;
 		if (e != hipSuccess) { ing->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return CIMBAR_HIP_EHIP; }
 		for (int j = 0; j < m; ++j) {
+			if (dev_png) {
+				ing->png_files += 1;
+				if (!sl.valid[(size_t)j]) ing->png_refused_host += 1;
+				else if (sl.h_status[j] != 0) { ing->png_refused_device += 1; sl.valid[(size_t)j] = 0; }
+			}
 			if (!sl.valid[(size_t)j]) { sl.h_masks[j] = 0; std::memset(sl.h_chunks + (size_t)j * ing->frame_bytes, 0, ing->frame_bytes); }
 			total += (int64_t)ing->chunk * __builtin_popcount(sl.h_masks[j] & 0xFFFu);
 		}
@@ -257,12 +316,29 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			cv.wait(lk, [&] { return filled[(size_t)k] == m; });
 			(void)t0;
 		}
-		hipError_t e = hipMemcpyAsync(sl.d_in, direct ? direct + (size_t)k * B * ing->frame : sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
-		if (e != hipSuccess) { ing->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
-		// "the frames are whatever hip_stream has produced up to here": the library's own stream waits for the copy
-		int r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, ing->copy_stream);
+		int r;
+		if (dev_png) {
+			// the compressed bytes and the descriptors go over on the copy stream; the slot's own stream inflates and un-filters them into
+			// d_in (so that consecutive batches' inflate passes overlap) and is what the decoder then waits for
+			const size_t zbytes = (zcur[(size_t)k].load() + 15) & ~(size_t)15;
+			ing->png_bytes += (int64_t)zbytes;
+			hipError_t e = zbytes ? hipMemcpyAsync(sl.d_z, sl.h_z, zbytes < ing->zcap ? zbytes : ing->zcap, hipMemcpyHostToDevice, ing->copy_stream) : hipSuccess;
+			if (e == hipSuccess) e = hipMemcpyAsync(sl.d_desc, sl.h_desc, sizeof(cimbar_hip_png_desc) * (size_t)m, hipMemcpyHostToDevice, ing->copy_stream);
+			if (e == hipSuccess) e = hipEventRecord(sl.copied, ing->copy_stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(sl.png_stream, sl.copied, 0);
+			if (e != hipSuccess) { ing->err = std::string("copy of the PNG streams: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
+			r = cimbar_hip_png_decode_batch(ing->device, sl.d_z, ing->zcap, sl.d_desc, m, sl.d_scratch, ing->scratch_stride, sl.d_in, ing->frame, sl.d_status, sl.png_stream);
+			if (r != 0) { ing->err = "cimbar_hip_png_decode_batch failed to launch"; rc = r; break; }
+			r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, sl.png_stream);
+		} else {
+			hipError_t e = hipMemcpyAsync(sl.d_in, direct ? direct + (size_t)k * B * ing->frame : sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
+			if (e != hipSuccess) { ing->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
+			// "the frames are whatever hip_stream has produced up to here": the library's own stream waits for the copy
+			r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, ing->copy_stream);
+		}
 		if (r == 0) r = cimbar_hip_pipeline_wait(ing->ctx, ing->out_stream, 0);
 		if (r != 0) { ing->err = std::string("decode: ") + cimbar_hip_last_error(ing->ctx); rc = r; break; }
+		if (dev_png) (void)hipMemcpyAsync(sl.h_status, sl.d_status, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, ing->out_stream);
 		(void)hipMemcpyAsync(sl.h_chunks, sl.d_chunks, (size_t)m * ing->frame_bytes, hipMemcpyDeviceToHost, ing->out_stream);
 		(void)hipMemcpyAsync(sl.h_masks, sl.d_masks, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, ing->out_stream);
 		(void)hipEventRecord(sl.done, ing->out_stream);
@@ -283,6 +359,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 	cv.notify_all();
 	for (auto& t : pool) t.join();
 	(void)hipStreamSynchronize(ing->copy_stream);
+	for (auto& sl : ing->slots) if (sl.png_stream) (void)hipStreamSynchronize(sl.png_stream);
 	(void)hipStreamSynchronize(ing->out_stream);
 	(void)cimbar_hip_pipeline_wait(ing->ctx, ing->out_stream, 0);
 	(void)hipStreamSynchronize(ing->out_stream);
@@ -305,10 +382,16 @@ int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_c
 
 int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out)
 {
-	if (!ctx || !out) return CIMBAR_HIP_EINVAL;
+	return cimbar_ingest_create_ex(ctx, threads, batch_frames, ring, CIMBAR_INGEST_PNG_HOST, 0, out);
+}
+
+int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, int png_mode, size_t zbytes_per_frame, cimbar_ingest** out)
+{
+	if (!ctx || !out || !(png_mode == CIMBAR_INGEST_PNG_HOST || png_mode == CIMBAR_INGEST_PNG_DEVICE)) return CIMBAR_HIP_EINVAL;
 	*out = nullptr;
 	cimbar_ingest* ing = new cimbar_ingest();
 	ing->ctx = ctx;
+	ing->png_mode = png_mode;
 	ing->device = cimbar_hip_device(ctx);
 	int32_t geo[CIMBAR_HIP_GEOMETRY_WORDS];
 	if (cimbar_hip_geometry(ctx, geo) != CIMBAR_HIP_GEOMETRY_WORDS) { delete ing; return CIMBAR_HIP_EINVAL; }
@@ -330,7 +413,7 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
 		std::fclose(fq);
 	}
 	ing->threads = threads > 0 ? threads : (hw > 128 ? 128 : hw);
-	ing->B = batch_frames > 0 ? batch_frames : 64;
+	ing->B = batch_frames > 0 ? batch_frames : (png_mode == CIMBAR_INGEST_PNG_DEVICE ? 512 : 64);
 	const int depth = cimbar_hip_pipeline_depth(ctx);
 	ing->R = ring > 0 ? ring : 3;
 	if (ing->R < 2) ing->R = 2;
@@ -340,9 +423,28 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
 	if (hipStreamCreateWithFlags(&ing->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
 	if (hipStreamCreateWithFlags(&ing->out_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
 	ing->slots.resize((size_t)ing->R);
+	const bool dev_png = png_mode == CIMBAR_INGEST_PNG_DEVICE;
+	if (dev_png) {
+		// room for the batch's compressed streams: a quarter of the decoded size per frame unless the caller knows better (a frame PNG is a
+		// tenth); a file that does not fit any more is skipped like one that cannot be read
+		const size_t per = zbytes_per_frame ? zbytes_per_frame : ing->frame / 4;
+		ing->zcap = ((size_t)ing->B * per + 4095) & ~(size_t)4095;
+		ing->scratch_stride = cimbar_hip_png_scratch_bytes(ing->fw, ing->fh, 6);     // RGBA is the widest form a frame can arrive in
+	}
 	for (auto& s : ing->slots) {
 		const size_t nb = (size_t)ing->B;
-		if (hipHostMalloc((void**)&s.h_in, nb * ing->frame, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
+		if (dev_png) {
+			if (hipHostMalloc((void**)&s.h_z, ing->zcap, hipHostMallocDefault) != hipSuccess) return fail("pinned PNG streams");
+			if (hipMalloc((void**)&s.d_z, ing->zcap) != hipSuccess) return fail("device PNG streams");
+			if (hipHostMalloc((void**)&s.h_desc, nb * sizeof(cimbar_hip_png_desc), hipHostMallocDefault) != hipSuccess) return fail("pinned descriptors");
+			if (hipMalloc((void**)&s.d_desc, nb * sizeof(cimbar_hip_png_desc)) != hipSuccess) return fail("device descriptors");
+			if (hipMalloc((void**)&s.d_scratch, nb * ing->scratch_stride) != hipSuccess) return fail("device scanlines");
+			if (hipHostMalloc((void**)&s.h_status, nb * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return fail("pinned status");
+			if (hipMalloc((void**)&s.d_status, nb * sizeof(int32_t)) != hipSuccess) return fail("device status");
+			if (hipStreamCreateWithFlags(&s.png_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+			if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return fail("event");
+			std::memset(s.h_desc, 0, nb * sizeof(cimbar_hip_png_desc));
+		} else if (hipHostMalloc((void**)&s.h_in, nb * ing->frame, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
 		if (hipMalloc((void**)&s.d_in, nb * ing->frame) != hipSuccess) return fail("device input");
 		if (hipHostMalloc((void**)&s.h_chunks, nb * ing->frame_bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned chunks");
 		if (hipMalloc((void**)&s.d_chunks, nb * ing->frame_bytes) != hipSuccess) return fail("device chunks");
@@ -367,6 +469,15 @@ void cimbar_ingest_destroy(cimbar_ingest* ing)
 		if (s.h_masks) (void)hipHostFree(s.h_masks);
 		if (s.d_masks) (void)hipFree(s.d_masks);
 		if (s.done) (void)hipEventDestroy(s.done);
+		if (s.h_z) (void)hipHostFree(s.h_z);
+		if (s.d_z) (void)hipFree(s.d_z);
+		if (s.h_desc) (void)hipHostFree(s.h_desc);
+		if (s.d_desc) (void)hipFree(s.d_desc);
+		if (s.d_scratch) (void)hipFree(s.d_scratch);
+		if (s.h_status) (void)hipHostFree(s.h_status);
+		if (s.d_status) (void)hipFree(s.d_status);
+		if (s.png_stream) (void)hipStreamDestroy(s.png_stream);
+		if (s.copied) (void)hipEventDestroy(s.copied);
 	}
 	if (ing->copy_stream) (void)hipStreamDestroy(ing->copy_stream);
 	if (ing->out_stream) (void)hipStreamDestroy(ing->out_stream);
@@ -379,8 +490,36 @@ int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, in
                                 cimbar_ingest_sink_fn sink, void* user)
 {
 	if (!ing || !paths || nfiles < 0) return CIMBAR_HIP_EINVAL;
-	auto fill = [&](int i, uint8_t* dst) -> bool {
+	if (ing->png_mode == CIMBAR_INGEST_PNG_DEVICE) {
+		// the host only walks the chunks and moves the IDAT bytes; inflate + un-filter happen on the device
+		auto fillz = [&](int i, cimbar_ingest::Slot& sl, int j, std::atomic<size_t>& cursor) -> bool {
+			thread_local std::vector<uint8_t> file;
+			thread_local PngInfo info;
+			cimbar_hip_png_desc& d = sl.h_desc[j];
+			std::memset(&d, 0, sizeof d);                   // (zlen 0: the device refuses the slot)
+			if (!read_file(paths[i], file)) return false;
+			if (png_walk(file.data(), file.size(), info) != 0) return false;
+			if (info.w != ing->fw || info.h != ing->fh) return false;
+			const size_t zal = (info.zlen + 15) & ~(size_t)15, need = zal + (info.ctype == 3 ? 768 : 0);
+			const size_t off = cursor.fetch_add(need);
+			if (off + need > ing->zcap) return false;       // the batch's compressed bytes do not fit: see cimbar_ingest_create_ex
+			uint8_t* dst = sl.h_z + off;
+			for (const auto& seg : info.idat) { std::memcpy(dst, seg.first, seg.second); dst += seg.second; }
+			std::memset(dst, 0, zal - info.zlen);
+			if (info.ctype == 3) {
+				uint8_t* pal = sl.h_z + off + zal;
+				std::memset(pal, 0, 768);
+				std::memcpy(pal, info.plte, (size_t)info.npal * 3);
+				d.pal_off = (uint32_t)(off + zal);
+			}
+			d.zoff = off; d.zlen = (uint32_t)info.zlen; d.width = info.w; d.height = info.h; d.color_type = info.ctype;
+			return true;
+		};
+		return run_pipeline(ing, nfiles, should_preprocess, color_correction, sink, user, fillz);
+	}
+	auto fill = [&](int i, cimbar_ingest::Slot& sl, int j, std::atomic<size_t>&) -> bool {
 		thread_local std::vector<uint8_t> file, idat, raw;
+		uint8_t* dst = sl.h_in + (size_t)j * ing->frame;
 		if (!read_file(paths[i], file)) return false;
 		unsigned w = 0, h = 0;
 		if (png_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0) return false;
@@ -394,12 +533,20 @@ int64_t cimbar_ingest_run_raw(cimbar_ingest* ing, const uint8_t* frames, int n, 
                               cimbar_ingest_sink_fn sink, void* user)
 {
 	if (!ing || !frames || n < 0) return CIMBAR_HIP_EINVAL;
-	auto fill = [&](int i, uint8_t* dst) -> bool { std::memcpy(dst, frames + (size_t)i * ing->frame, ing->frame); return true; };
+	if (ing->png_mode == CIMBAR_INGEST_PNG_DEVICE) { ing->err = "a device-PNG ingest has no pinned frame ring: create a host-mode one for raw frames"; return CIMBAR_HIP_EINVAL; }
+	auto fill = [&](int i, cimbar_ingest::Slot& sl, int j, std::atomic<size_t>&) -> bool { std::memcpy(sl.h_in + (size_t)j * ing->frame, frames + (size_t)i * ing->frame, ing->frame); return true; };
 	// frames in page-locked memory (hipHostMalloc, hipHostRegister, torch's pin_memory) are copied to the device where they lie
 	hipPointerAttribute_t attr;
 	const bool pinned = hipPointerGetAttributes(&attr, frames) == hipSuccess && attr.type == hipMemoryTypeHost;
 	if (!pinned) (void)hipGetLastError();   // an ordinary pointer is reported as an error: clear it
 	return run_pipeline(ing, n, should_preprocess, color_correction, sink, user, fill, pinned ? frames : nullptr);
+}
+
+int cimbar_ingest_png_stats(const cimbar_ingest* ing, int64_t out4[4])
+{
+	if (!ing || !out4) return CIMBAR_HIP_EINVAL;
+	out4[0] = ing->png_files; out4[1] = ing->png_refused_host; out4[2] = ing->png_refused_device; out4[3] = ing->png_bytes;
+	return 0;
 }
 
 int cimbar_ingest_timings(const cimbar_ingest* ing, double out3[3])

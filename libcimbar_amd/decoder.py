@@ -28,7 +28,15 @@ EXPORTS = (
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
     "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
+    "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch",
 )
+PNG_EHEADER, PNG_ESTREAM, PNG_ECODES, PNG_ESIZE, PNG_ECHECK = -30, -31, -32, -33, -34
+
+
+class PngDesc(ctypes.Structure):
+    """cimbar_hip_png_desc"""
+    _fields_ = [("zoff", ctypes.c_uint64), ("zlen", ctypes.c_uint32), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("color_type", ctypes.c_uint32), ("pal_off", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class CimbarHipError(RuntimeError):
@@ -107,9 +115,80 @@ def load_library(path=None):
     lib.cimbar_hip_set_template.restype = i32
     lib.cimbar_hip_encode_batch.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     lib.cimbar_hip_encode_batch.restype = i32
+    lib.cimbar_hip_png_scratch_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    lib.cimbar_hip_png_scratch_bytes.restype = sz
+    lib.cimbar_hip_png_decode_batch.argtypes = [i32, vp, sz, vp, i32, vp, sz, vp, sz, vp, vp]
+    lib.cimbar_hip_png_decode_batch.restype = i32
     if path is None:
         _lib = lib
     return lib
+
+
+def png_split(png):
+    """PNG bytes -> (width, height, colour type, bit depth, interlace, zlib stream = the concatenated IDAT payloads, palette bytes or None):
+    the chunk walk the ingest library's device mode does on the host"""
+    import struct
+    if png[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, z, pal, hdr = 8, [], None, None
+    while pos + 12 <= len(png):
+        n, tag = struct.unpack(">I4s", png[pos:pos + 8])
+        body = png[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"PLTE":
+            pal = bytes(body)
+        elif tag == b"IDAT":
+            z.append(body)
+        elif tag == b"IEND":
+            break
+        pos += 12 + n
+    w, h, depth, ctype, _c, _f, interlace = hdr
+    return w, h, ctype, depth, interlace, b"".join(z), pal
+
+
+def png_decode_batch_device(pngs, device=0):
+    """PNG files (bytes) -> (list of (h, w, 3) uint8 arrays or None, status array): cimbar_hip_png_decode_batch on torch device buffers.
+    Test / bench plumbing: packs the streams the way libcimbar_ingest.so's device mode does."""
+    import torch
+    lib = load_library()
+    n = len(pngs)
+    desc = (PngDesc * n)()
+    blob = bytearray()
+    dims = []
+    for i, png in enumerate(pngs):
+        w, h, ctype, depth, interlace, z, pal = png_split(png)
+        if depth != 8 or interlace:
+            raise ValueError("the device decoder takes 8-bit non-interlaced PNGs")
+        while len(blob) % 16:
+            blob.append(0)
+        desc[i].zoff, desc[i].zlen, desc[i].width, desc[i].height, desc[i].color_type = len(blob), len(z), w, h, ctype
+        blob += z
+        if ctype == 3:
+            while len(blob) % 16:
+                blob.append(0)
+            desc[i].pal_off = len(blob)
+            blob += (pal or b"") + bytes(768 - len(pal or b""))
+        dims.append((w, h, ctype))
+    while len(blob) % 16:
+        blob.append(0)
+    dev = torch.device("cuda", device)
+    d_z = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(dev)
+    d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
+    sstride = max(int(lib.cimbar_hip_png_scratch_bytes(w, h, ct)) for w, h, ct in dims)
+    rstride = (max(w * h * 3 for w, h, _ in dims) + 15) & ~15
+    d_scratch = torch.empty(n * sstride, dtype=torch.uint8, device=dev)
+    d_rgb = torch.zeros(n * rstride, dtype=torch.uint8, device=dev)
+    d_status = torch.full((n,), 12345, dtype=torch.int32, device=dev)
+    rc = lib.cimbar_hip_png_decode_batch(device, d_z.data_ptr(), d_z.numel(), d_desc.data_ptr(), n, d_scratch.data_ptr(), sstride, d_rgb.data_ptr(), rstride,
+                                         d_status.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise CimbarHipError(f"cimbar_hip_png_decode_batch: {rc}")
+    torch.cuda.synchronize(dev)
+    status = d_status.cpu().numpy()
+    rgb = d_rgb.cpu().numpy()
+    out = [rgb[i * rstride:i * rstride + w * h * 3].reshape(h, w, 3).copy() if status[i] == 0 else None for i, (w, h, _) in enumerate(dims)]
+    return out, status
 
 
 def tile_hashes():

@@ -10,7 +10,8 @@ from . import decoder
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_ingest.so")
 EXPORTS = ("cimbar_png_decode", "cimbar_ingest_create", "cimbar_ingest_destroy", "cimbar_ingest_last_error", "cimbar_ingest_run_files",
-           "cimbar_ingest_run_raw", "cimbar_ingest_timings")
+           "cimbar_ingest_run_raw", "cimbar_ingest_timings", "cimbar_ingest_create_ex", "cimbar_ingest_png_stats")
+PNG_HOST, PNG_DEVICE = 0, 1
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int)
 
 _lib = None
@@ -28,6 +29,10 @@ def load_library():
         L.cimbar_png_decode.restype = i32
         L.cimbar_ingest_create.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
         L.cimbar_ingest_create.restype = i32
+        L.cimbar_ingest_create_ex.argtypes = [vp, i32, i32, i32, i32, sz, ctypes.POINTER(vp)]
+        L.cimbar_ingest_create_ex.restype = i32
+        L.cimbar_ingest_png_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
+        L.cimbar_ingest_png_stats.restype = i32
         L.cimbar_ingest_destroy.argtypes = [vp]
         L.cimbar_ingest_destroy.restype = None
         L.cimbar_ingest_last_error.argtypes = [vp]
@@ -58,12 +63,14 @@ def png_decode(data):
 
 
 class Ingest:
-    def __init__(self, dec, threads=0, batch_frames=64, ring=3):
+    def __init__(self, dec, threads=0, batch_frames=64, ring=3, png_device=False, zbytes_per_frame=0):
+        """png_device: PNG files are inflated and un-filtered on the GPU (cimbar_ingest_create_ex, CIMBAR_INGEST_PNG_DEVICE)"""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
-        rc = self._lib.cimbar_ingest_create(dec._ctx, int(threads), int(batch_frames), int(ring), ctypes.byref(self._h))
+        rc = self._lib.cimbar_ingest_create_ex(dec._ctx, int(threads), int(batch_frames), int(ring), PNG_DEVICE if png_device else PNG_HOST,
+                                               int(zbytes_per_frame), ctypes.byref(self._h))
         if rc != 0:
-            raise decoder.CimbarHipError(f"cimbar_ingest_create: {rc}")
+            raise decoder.CimbarHipError(f"cimbar_ingest_create_ex: {rc}")
         self._dec = dec
 
     def close(self):
@@ -110,6 +117,11 @@ class Ingest:
         if rc < 0:
             raise decoder.CimbarHipError(f"cimbar_ingest_run_raw: {rc} {self._lib.cimbar_ingest_last_error(self._h).decode()}")
         return int(rc)
+
+    def png_stats(self):
+        out = (ctypes.c_int64 * 4)()
+        self._lib.cimbar_ingest_png_stats(self._h, out)
+        return {"files": out[0], "refused_by_host_walk": out[1], "refused_by_device": out[2], "bytes_to_device": out[3]}
 
     def timings(self):
         out = (ctypes.c_double * 3)()

@@ -1,0 +1,152 @@
+"""PNG test inputs for the device PNG decoder (csrc/png.hip.inc) and its CPU model (tools/png_model.cpp): images written by Pillow at several
+compression levels and colour types, and hand-assembled PNGs that force every filter type, every deflate block type (stored / fixed / dynamic,
+zlib's strategies), small windows, long overlapped runs, odd sizes. Each case = (name, png bytes, expected (h, w, 3) RGB array)."""
+import io
+import struct
+import zlib
+
+import numpy as np
+
+
+def _chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def _paeth(a, b, c):
+    p = a.astype(np.int32) + b - c
+    pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+    return np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+
+
+def filter_rows(img, filters):
+    """img (h, w, bpp) uint8, filters[h] in 0..4 -> the filtered scanlines with their type bytes"""
+    h, w, bpp = img.shape
+    flat = img.reshape(h, w * bpp).astype(np.int32)
+    out = bytearray()
+    zero = np.zeros(w * bpp, np.int32)
+    for y in range(h):
+        cur = flat[y]
+        up = flat[y - 1] if y else zero
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if w * bpp > bpp else np.zeros_like(cur)
+        if w * bpp <= bpp:
+            left = np.zeros_like(cur)
+        upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if w * bpp > bpp else np.zeros_like(cur)
+        ft = int(filters[y])
+        pred = [zero, left, up, (left + up) >> 1, _paeth(left, up, upleft)][ft]
+        out.append(ft)
+        out += bytes(((cur - pred) & 255).astype(np.uint8))
+    return bytes(out)
+
+
+def make_png(img, filters, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=15, mem=8, ctype=None, palette=None, idat_split=0):
+    h, w, bpp = img.shape
+    if ctype is None:
+        ctype = {1: 0, 3: 2, 4: 6}[bpp]
+    raw = filter_rows(img, filters)
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem, strategy)
+    z = co.compress(raw) + co.flush()
+    png = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if palette is not None:
+        png += _chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    if idat_split:
+        for i in range(0, len(z), idat_split):
+            png += _chunk(b"IDAT", z[i:i + idat_split])
+    else:
+        png += _chunk(b"IDAT", z)
+    return png + _chunk(b"IEND", b"")
+
+
+def to_rgb(img, ctype, palette=None):
+    if ctype == 2:
+        return img
+    if ctype == 6:
+        return img[..., :3]
+    if ctype == 0:
+        return np.repeat(img, 3, axis=2)
+    pal = np.asarray(palette, np.uint8).reshape(-1, 3)
+    idx = img[..., 0]
+    return pal[np.minimum(idx, len(pal) - 1) * (idx < len(pal))]
+
+
+def cases(frame=None, seed=7, big=True):
+    """frame: a (1024, 1024, 3) cimbar frame to cut realistic content from (or None: synthetic tile-like content)"""
+    g = np.random.default_rng(seed)
+    out = []
+    if frame is None:
+        tile = g.integers(0, 2, (8, 8, 1), dtype=np.uint8) * g.integers(0, 256, (1, 1, 3), dtype=np.uint8)
+        frame = np.tile(np.pad(tile, ((0, 1), (0, 1), (0, 0))), (114, 114, 1))[:1024, :1024]
+    noise = g.integers(0, 256, (90, 70, 3), dtype=np.uint8)
+    crop = np.ascontiguousarray(frame[100:230, 40:300])
+    black = np.zeros((70, 400, 3), np.uint8)
+    grad = (np.add.outer(np.arange(140), np.arange(260)) % 256).astype(np.uint8)[..., None].repeat(3, 2)
+    named = {"crop": crop, "noise": noise, "black": black, "grad": grad}
+    # every filter type on every kind of content, default deflate
+    for nm, im in named.items():
+        h = im.shape[0]
+        for ft in range(5):
+            out.append((f"{nm}_f{ft}", make_png(im, [ft] * h), im))
+        out.append((f"{nm}_fmix", make_png(im, g.integers(0, 5, h)), im))
+    # deflate variety on the cimbar crop and the noise (mixed filters)
+    mixc, mixn = g.integers(0, 5, crop.shape[0]), g.integers(0, 5, noise.shape[0])
+    for lvl in (0, 1, 2, 4, 9):
+        out.append((f"crop_l{lvl}", make_png(crop, mixc, level=lvl), crop))
+        out.append((f"noise_l{lvl}", make_png(noise, mixn, level=lvl), noise))
+    for nm, st in (("fixed", zlib.Z_FIXED), ("huff", zlib.Z_HUFFMAN_ONLY), ("rle", zlib.Z_RLE), ("filtered", zlib.Z_FILTERED)):
+        out.append((f"crop_{nm}", make_png(crop, mixc, strategy=st), crop))
+        out.append((f"black_{nm}", make_png(black, [0] * black.shape[0], strategy=st), black))
+    for wb in (9, 10, 12):
+        out.append((f"crop_w{wb}", make_png(crop, mixc, wbits=wb), crop))
+    out.append(("crop_mem1", make_png(crop, mixc, mem=1, level=1), crop))          # many small blocks
+    out.append(("crop_idat7", make_png(crop, mixc, idat_split=7), crop))           # IDAT in 7-byte pieces
+    out.append(("crop_idat4k", make_png(crop, mixc, idat_split=4096), crop))
+    # sizes around the 64-row bands and tiny widths
+    for (h, w) in ((1, 1), (1, 5), (2, 2), (63, 3), (64, 64), (65, 33), (128, 7), (129, 1), (200, 2)):
+        im = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out.append((f"rgb_{h}x{w}", make_png(im, g.integers(0, 5, h)), im))
+    # other colour types
+    rgba = g.integers(0, 256, (77, 50, 4), dtype=np.uint8)
+    rgba[..., :3] = crop[:77, :50]
+    out.append(("rgba", make_png(rgba, g.integers(0, 5, 77)), to_rgb(rgba, 6)))
+    gray = np.ascontiguousarray(crop[:, :, :1])
+    out.append(("gray", make_png(gray, g.integers(0, 5, gray.shape[0])), to_rgb(gray, 0)))
+    pal = g.integers(0, 256, (16, 3), dtype=np.uint8)
+    pimg = g.integers(0, 16, (66, 90, 1), dtype=np.uint8)
+    out.append(("palette", make_png(pimg, g.integers(0, 5, 66), ctype=3, palette=pal), to_rgb(pimg, 3, pal)))
+    # Pillow's own writer
+    try:
+        from PIL import Image
+        for lvl in (1, 6):
+            buf = io.BytesIO()
+            Image.fromarray(crop).save(buf, format="PNG", compress_level=lvl)
+            out.append((f"pillow_l{lvl}", buf.getvalue(), crop))
+        if big:
+            for lvl in (1, 6):
+                buf = io.BytesIO()
+                Image.fromarray(frame).save(buf, format="PNG", compress_level=lvl)
+                out.append((f"pillow_frame_l{lvl}", buf.getvalue(), frame))
+    except ImportError:
+        pass
+    if big:
+        out.append(("frame_fmix", make_png(frame, g.integers(0, 5, frame.shape[0]), level=1), frame))
+        fn = np.clip(frame.astype(np.int16) + g.normal(0, 30, frame.shape).astype(np.int16), 0, 255).astype(np.uint8)
+        out.append(("frame_noisy", make_png(fn, g.integers(0, 5, fn.shape[0]), level=1), fn))
+    return out
+
+
+def corrupt_cases(seed=11):
+    """streams a decoder must refuse (never crash on, never run away with): returns (name, png bytes)"""
+    g = np.random.default_rng(seed)
+    im = g.integers(0, 256, (40, 30, 3), dtype=np.uint8)
+    good = make_png(im, [0] * 40)
+    out = []
+    i = good.index(b"IDAT") + 4
+    n = struct.unpack(">I", good[i - 8:i - 4])[0]
+    for k in range(12):
+        b = bytearray(good)
+        pos = i + 2 + int(g.integers(0, n - 6))
+        b[pos] ^= 1 << int(g.integers(0, 8))
+        out.append((f"bitflip{k}", bytes(b)))
+    b = bytearray(good); b[i + 2] = (b[i + 2] & 0xF9) | 0x06
+    out.append(("btype3", bytes(b)))
+    out.append(("truncated", good[:i + n // 2] + good[i + n:]))
+    return out

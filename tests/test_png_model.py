@@ -1,0 +1,54 @@
+"""tools/png_model.cpp -- the CPU model of the device PNG decoder's two algorithms (lane-parallel canonical Huffman decode over 64-dword
+input chunks, 32 KiB ring with 4 KiB flushes and running Adler-32, periodic overlapped copies; the skewed one-row-per-lane un-filter) --
+against images whose pixels are known: every filter type, every deflate block type and zlib strategy, small windows, split IDATs, odd
+sizes, Pillow's writer. The kernels in csrc/png.hip.inc restate the model; tests/test_gpu_png.py runs the same cases on the device."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import png_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("pngmodel") / "libpng_model.so")
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "png_model.cpp")], check=True)
+    L = ctypes.CDLL(so)
+    L.png_model_decode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint),
+                                   ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.c_float]
+    return L
+
+
+def decode(L, png, scale=1.0):
+    buf = np.frombuffer(png, np.uint8)
+    w, h, b = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+    rc = L.png_model_decode(buf.ctypes.data, buf.size, None, 0, w, h, b, scale)
+    if rc:
+        return rc, None
+    out = np.zeros((h.value, w.value, b.value), np.uint8)
+    rc = L.png_model_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.size, w, h, b, scale)
+    return rc, out
+
+
+@pytest.mark.parametrize("scale", [1.0, 1.0 + 2e-7, 1.0 - 2e-7])   # the device's v_rcp_f32 is not exactly rounded: the j mod dist fix-up must absorb it
+def test_model_decodes_every_case(model, synth, scale):
+    from tests.frames import clean_frames
+    _p, frames = clean_frames(synth, 1, seed=5151)
+    for name, png, want in png_cases.cases(frames[0], big=(scale == 1.0)):
+        rc, got = decode(model, png, scale)
+        assert rc == 0, (name, rc)
+        if name == "palette":
+            continue                     # (the model stops at the un-filtered indices)
+        rgb = got if got.shape[2] == 3 else got[..., :3] if got.shape[2] == 4 else np.repeat(got, 3, axis=2)
+        assert (rgb == want).all(), name
+
+
+def test_model_refuses_damaged_streams(model):
+    for name, png in png_cases.corrupt_cases():
+        rc, _ = decode(model, png)
+        assert rc != 0, name

@@ -1,0 +1,354 @@
+// png_model.cpp -- CPU model of the DEVICE PNG decoder's algorithm (csrc/png.hip.inc), statement for statement where the arithmetic matters:
+// lane-parallel canonical Huffman decode (per-length first / count / base), the 64-dword input chunks and the refill rule, the 32 KiB ring
+// with 4 KiB flushes, the periodic overlapped copy (float reciprocal + correction for j mod dist) and the skewed (one row per lane) un-filter.
+// Development aid: built by tests/test_png_model.py with g++ and fuzzed against zlib / Pillow on the CPU, so that what is left to find on
+// the GPU is plumbing, not arithmetic. Not part of the product and not an oracle for the decode path.
+//   g++ -O2 -shared -fPIC -o /tmp/libpng_model.so tools/png_model.cpp
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int WIN = 32768, WMASK = WIN - 1, FLUSH = 4096;
+
+enum { PNG_OK = 0, E_BTYPE = -1, E_STORED = -2, E_OVERSUB = -3, E_INCOMPLETE = -4, E_CODE = -5, E_DIST = -6, E_OUTSIZE = -7, E_INPUT = -8, E_HEADER = -9, E_NOEOB = -10,
+       E_REPEAT = -11, E_FILTER = -12, E_ADLER = -13 };
+
+struct Canon {           // what lane L (1..15) holds
+	uint32_t first[16];  // first code of length L
+	uint32_t count[16];
+	int32_t base[16];    // index into sorted[] of the first symbol of length L, minus first[L]
+	uint16_t sorted[320];
+	int maxlen;
+};
+
+// lengths[n] -> canonical tables; zlib's inflate_table rules for what is an error (inftrees.c): over-subscribed always; incomplete unless it is
+// a distance (or any non-CODES) set with a single 1-bit code... zlib: "if (left > 0 && (type == CODES || max != 1)) return -1"
+int canon_build(Canon& c, const uint8_t* lengths, int n, bool is_codes)
+{
+	for (int L = 0; L < 16; ++L) { c.count[L] = 0; c.first[L] = 0; c.base[L] = 0; }
+	for (int s = 0; s < n; ++s) c.count[lengths[s]]++;
+	c.count[0] = 0;
+	int maxlen = 0;
+	for (int L = 1; L < 16; ++L) if (c.count[L]) maxlen = L;
+	c.maxlen = maxlen;
+	if (maxlen == 0) return PNG_OK;          // no codes at all: an error only when a code is needed (zlib fills the table with invalid-code entries)
+	int left = 1;
+	for (int L = 1; L < 16; ++L) { left <<= 1; left -= (int)c.count[L]; if (left < 0) return E_OVERSUB; }
+	if (left > 0 && (is_codes || maxlen != 1)) return E_INCOMPLETE;
+	uint32_t code = 0, off = 0;
+	for (int L = 1; L < 16; ++L) {
+		c.first[L] = code;
+		c.base[L] = (int32_t)off - (int32_t)code;
+		code = (code + c.count[L]) << 1;
+		off += c.count[L];
+	}
+	// sorted by (length, symbol): the device does this with ballots over 64-symbol groups; the order is the same
+	uint32_t next[16];
+	{ uint32_t o = 0; for (int L = 1; L < 16; ++L) { next[L] = o; o += c.count[L]; } }
+	for (int s = 0; s < n; ++s) if (lengths[s]) c.sorted[next[lengths[s]]++] = (uint16_t)s;
+	return PNG_OK;
+}
+
+struct BitReader {
+	const uint32_t* in;     // the stream, dword-aligned start
+	size_t nwords, widx;
+	uint64_t bb;
+	int nb;
+	bool overrun;
+	uint32_t next_dword() { if (widx >= nwords) { if (widx > nwords + 2) overrun = true; ++widx; return 0; } return in[widx++]; }
+	void refill() { if (nb <= 32) { bb |= (uint64_t)next_dword() << nb; nb += 32; } }      // afterwards nb >= 33: a caller may take up to 32 bits
+	uint32_t peek(int n) const { return (uint32_t)(bb & ((1ull << n) - 1ull)); }
+	void drop(int n) { bb >>= n; nb -= n; }
+	uint32_t get(int n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+uint32_t rev15(uint32_t v)   // bit-reverse the low 15 bits (the device: v_bfrev_b32 >> 17)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 15; ++i) r |= ((v >> i) & 1u) << (14 - i);
+	return r;
+}
+
+// one symbol: every lane L tests "the first L bits are a code of length L"; the lowest such L wins
+int canon_decode(const Canon& c, BitReader& br, int* sym)
+{
+	const uint32_t r = rev15(br.peek(15));
+	for (int L = 1; L <= 15; ++L) {                 // (lanes)
+		const uint32_t codeL = r >> (15 - L);
+		if (codeL - c.first[L] < c.count[L]) {
+			*sym = c.sorted[(int32_t)codeL + c.base[L]];
+			br.drop(L);
+			return PNG_OK;
+		}
+	}
+	return E_CODE;
+}
+
+const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+unsigned long long g_stats[8];   // literals, matches, match bytes, blocks, stored bytes, overlapped matches, dynamic blocks
+
+struct Out {
+	uint8_t win[WIN];
+	uint8_t* glob;
+	uint32_t op, cap;
+	void flush_to(uint32_t upto)      // [flushed, upto) ring -> global
+	{
+		for (uint32_t q = flushed; q < upto; q += FLUSH) adler_segment(q, upto - q < (uint32_t)FLUSH ? upto : q + FLUSH);
+		for (uint32_t p = flushed; p < upto; ++p) glob[p] = win[p & WMASK];
+		flushed = upto;
+	}
+	uint32_t flushed;
+	uint32_t a1 = 1, a2 = 0;            // Adler-32 of everything flushed so far
+	void adler_segment(uint32_t from, uint32_t upto)
+	{
+		// per segment of n <= 4096 bytes: A' = A + sum d_i, B' = B + n*A + sum (n - i) d_i  (both sums < 2^32: lanes add their share, one wave reduction)
+		const uint32_t n = upto - from;
+		uint32_t s1 = 0, s2 = 0;
+		for (uint32_t i = 0; i < n; ++i) { const uint32_t d = win[(from + i) & WMASK]; s1 += d; s2 += (n - i) * d; }
+		a2 = (uint32_t)(((uint64_t)a2 + (uint64_t)n * a1 + s2) % 65521u);
+		a1 = (a1 + s1) % 65521u;
+	}
+	void after(uint32_t before) { if ((op ^ before) & ~(uint32_t)(FLUSH - 1)) flush_to(op & ~(uint32_t)(FLUSH - 1)); }
+};
+
+// j mod d for 0 <= j < 322, 1 <= d < 32768, the way the device does it (v_rcp_f32 is not exact: model it with a perturbed reciprocal too)
+inline uint32_t modsmall(uint32_t j, uint32_t d, float rcp)
+{
+	int q = (int)((float)j * rcp);
+	int r = (int)j - q * (int)d;
+	if (r < 0) r += (int)d;
+	if (r >= (int)d) r -= (int)d;
+	return (uint32_t)r;
+}
+
+int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect, float rcp_scale)
+{
+	if (zlen < 2) return E_HEADER;
+	if ((zs[0] & 15) != 8 || (zs[0] >> 4) > 7 || ((zs[0] << 8) | zs[1]) % 31 != 0 || (zs[1] & 0x20)) return E_HEADER;
+	std::vector<uint32_t> words((zlen + 3) / 4 + 1, 0);
+	std::memcpy(words.data(), zs, zlen);
+	BitReader br{words.data(), (zlen + 3) / 4, 0, 0, 0, false};
+	br.refill();
+	br.drop(16);                                  // CMF, FLG
+	static Out o;
+	o.glob = out; o.op = 0; o.cap = expect; o.flushed = 0; o.a1 = 1; o.a2 = 0;
+	for (auto& v : g_stats) v = 0;
+	Canon cl, ll, dd;
+	uint8_t lengths[320];
+	for (;;) {
+		br.refill();
+		const uint32_t bfinal = br.get(1), btype = br.get(2);
+		if (btype == 3) return E_BTYPE;
+		g_stats[3]++; if (btype == 2) g_stats[6]++;
+		if (btype == 0) {
+			br.drop(br.nb & 7);
+			br.refill();
+			const uint32_t len = br.get(16);
+			br.refill();
+			const uint32_t nlen = br.get(16);
+			if ((len ^ nlen) != 0xFFFFu) return E_STORED;
+			// the bytes follow at byte position 4 * widx - nb / 8 of the stream
+			const size_t bpos = br.widx * 4 - (size_t)(br.nb / 8);
+			if (bpos + len > zlen) return E_INPUT;
+			if (o.op + len > o.cap) return E_OUTSIZE;
+			g_stats[4] += len;
+			for (uint32_t c0 = 0; c0 < len; c0 += 64) {          // (64 lanes per pass)
+				const uint32_t before = o.op, m = len - c0 < 64 ? len - c0 : 64;
+				for (uint32_t l = 0; l < m; ++l) o.win[(o.op + l) & WMASK] = zs[bpos + c0 + l];
+				o.op += m;
+				o.after(before);
+			}
+			const size_t np = bpos + len;
+			br.widx = np / 4; br.bb = 0; br.nb = 0;
+			br.refill();
+			br.drop((int)(8 * (np % 4)));
+		} else {
+			if (btype == 1) {
+				for (int s = 0; s < 144; ++s) lengths[s] = 8;
+				for (int s = 144; s < 256; ++s) lengths[s] = 9;
+				for (int s = 256; s < 280; ++s) lengths[s] = 7;
+				for (int s = 280; s < 288; ++s) lengths[s] = 8;
+				int rc = canon_build(ll, lengths, 288, false);
+				if (rc) return rc;
+				for (int s = 0; s < 32; ++s) lengths[s] = 5;              // (zlib's fixed distance table has 32 entries too; 30 and 31 are invalid when met)
+				rc = canon_build(dd, lengths, 32, false);
+				if (rc) return rc;
+			} else {
+				br.refill();
+				const int hlit = (int)br.get(5) + 257, hdist = (int)br.get(5) + 1, hclen = (int)br.get(4) + 4;
+				if (hlit > 286 || hdist > 30) return E_HEADER;
+				uint8_t cll[19];
+				std::memset(cll, 0, sizeof cll);
+				for (int k = 0; k < hclen; ++k) { br.refill(); cll[CLORDER[k]] = (uint8_t)br.get(3); }
+				int rc = canon_build(cl, cll, 19, true);
+				if (rc) return rc;
+				int n = 0;
+				while (n < hlit + hdist) {
+					br.refill();
+					int sym;
+					rc = canon_decode(cl, br, &sym);
+					if (rc) return rc;
+					if (sym < 16) lengths[n++] = (uint8_t)sym;
+					else {
+						int rep, val = 0;
+						if (sym == 16) { if (n == 0) return E_REPEAT; val = lengths[n - 1]; rep = 3 + (int)br.get(2); }
+						else if (sym == 17) rep = 3 + (int)br.get(3);
+						else rep = 11 + (int)br.get(7);
+						if (n + rep > hlit + hdist) return E_REPEAT;
+						while (rep--) lengths[n++] = (uint8_t)val;
+					}
+				}
+				if (lengths[256] == 0) return E_NOEOB;
+				rc = canon_build(ll, lengths, hlit, false);
+				if (rc) return rc;
+				rc = canon_build(dd, lengths + hlit, hdist, false);
+				if (rc) return rc;
+			}
+			for (;;) {
+				br.refill();
+				int sym;
+				int rc = canon_decode(ll, br, &sym);
+				if (rc) return rc;
+				if (sym < 256) {
+					if (o.op >= o.cap) return E_OUTSIZE;
+					const uint32_t before = o.op;
+					o.win[o.op & WMASK] = (uint8_t)sym;
+				g_stats[0]++;
+					o.op += 1;
+					o.after(before);
+					continue;
+				}
+				if (sym == 256) break;
+				if (sym > 285) return E_CODE;
+				const uint32_t len = LBASE[sym - 257] + br.get(LEXT[sym - 257]);   // <= 15 + 5 bits since the refill
+				br.refill();
+				int ds;
+				rc = canon_decode(dd, br, &ds);
+				if (rc) return rc;
+				if (ds > 29) return E_CODE;
+				const uint32_t dist = DBASE[ds] + br.get(DEXT[ds]);                   // <= 15 + 13
+				if (dist > o.op) return E_DIST;
+				if (o.op + len > o.cap) return E_OUTSIZE;
+				const float rcp = rcp_scale / (float)dist;
+				g_stats[1]++; g_stats[2] += len; if (dist < len) g_stats[5]++;
+				const uint32_t before = o.op;
+				for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+					uint8_t tmp[64];
+					const uint32_t m = len - c0 < 64 ? len - c0 : 64;
+					for (uint32_t l = 0; l < m; ++l) {             // all lanes read ...
+						const uint32_t j = c0 + l, r = dist >= len ? j : modsmall(j, dist, rcp);
+						tmp[l] = o.win[(before - dist + r) & WMASK];
+					}
+					for (uint32_t l = 0; l < m; ++l) o.win[(before + c0 + l) & WMASK] = tmp[l];   // ... then all lanes write
+				}
+				o.op += len;
+				o.after(before);
+			}
+		}
+		if (bfinal) break;
+	}
+	if (br.overrun) return E_INPUT;
+	o.flush_to(o.op);
+	if (o.op != expect) return E_OUTSIZE;
+	// the Adler-32 of the inflated bytes follows the last block at the next byte boundary, big-endian (RFC 1950)
+	br.drop(br.nb & 7);
+	uint32_t want = 0;
+	for (int k = 0; k < 4; ++k) { br.refill(); want = (want << 8) | br.get(8); }
+	if (br.overrun) return E_INPUT;
+	return want == ((o.a2 << 16) | o.a1) ? PNG_OK : E_ADLER;
+}
+
+inline int paeth(int a, int b, int c)
+{
+	const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+	return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// the skewed un-filter: lane l owns row 64*band + l and is l pixels behind the lane above; "up" travels lane to lane, the band's last row
+// goes through a boundary row in memory. raw = h * (1 + w*bpp) filtered bytes, un-filtered in `unf` (h * w * bpp)
+int unfilter_model(const uint8_t* raw, uint8_t* unf, int w, int h, int bpp)
+{
+	const int rb = w * bpp;
+	std::vector<uint8_t> boundary((size_t)rb, 0);
+	for (int band = 0; band * 64 < h; ++band) {
+		uint32_t prev_out[64], prev_b[64], a[64];
+		for (int l = 0; l < 64; ++l) prev_out[l] = prev_b[l] = a[l] = 0;
+		std::vector<uint8_t> newboundary((size_t)rb, 0);
+		for (int t = 0; t < w + 63; ++t) {
+			uint32_t cur_out[64], cur_b[64];
+			for (int l = 0; l < 64; ++l) {
+				const int row = band * 64 + l, x = t - l;
+				cur_out[l] = 0; cur_b[l] = 0;
+				uint32_t b;                                   // packed channels of the pixel above
+				if (l > 0) b = prev_out[l - 1];
+				else {
+					b = 0;
+					if (band > 0 && x >= 0 && x < w) for (int ch = 0; ch < bpp; ++ch) b |= (uint32_t)boundary[(size_t)x * bpp + ch] << (8 * ch);
+				}
+				cur_b[l] = b;
+				if (row >= h || x < 0 || x >= w) continue;
+				const uint32_t c = prev_b[l];                 // the pixel above-left = what was "above" one step ago
+				const uint8_t ft = raw[(size_t)row * (rb + 1)];
+				if (ft > 4) return E_FILTER;
+				uint32_t o = 0;
+				for (int ch = 0; ch < bpp; ++ch) {
+					const int f = raw[(size_t)row * (rb + 1) + 1 + (size_t)x * bpp + ch];
+					const int av = x > 0 ? (int)((a[l] >> (8 * ch)) & 255u) : 0, bv = (int)((b >> (8 * ch)) & 255u), cv = x > 0 ? (int)((c >> (8 * ch)) & 255u) : 0;
+					int pred = 0;
+					switch (ft) { case 1: pred = av; break; case 2: pred = bv; break; case 3: pred = (av + bv) >> 1; break; case 4: pred = paeth(av, bv, cv); break; default: break; }
+					o |= (uint32_t)((f + pred) & 255) << (8 * ch);
+				}
+				cur_out[l] = o;
+				a[l] = o;
+				for (int ch = 0; ch < bpp; ++ch) unf[((size_t)row * w + x) * bpp + ch] = (uint8_t)(o >> (8 * ch));
+				if (l == 63) for (int ch = 0; ch < bpp; ++ch) newboundary[(size_t)x * bpp + ch] = (uint8_t)(o >> (8 * ch));
+			}
+			for (int l = 0; l < 64; ++l) { prev_out[l] = cur_out[l]; prev_b[l] = cur_b[l]; }
+		}
+		boundary.swap(newboundary);
+	}
+	return PNG_OK;
+}
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+}  // namespace
+
+// PNG (8-bit gray / RGB / RGBA / palette, non-interlaced) -> un-filtered samples (h*w*bpp); returns 0 or a negative code; *pw,*ph,*pbpp set
+extern "C" int png_model_decode(const uint8_t* png, size_t len, uint8_t* unf, size_t cap, unsigned* pw, unsigned* ph, unsigned* pbpp, float rcp_scale)
+{
+	if (len < 33 || std::memcmp(png, "\x89PNG\r\n\x1a\n", 8) != 0) return E_HEADER;
+	size_t pos = 8;
+	unsigned w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+	std::vector<uint8_t> idat;
+	while (pos + 12 <= len) {
+		const uint32_t clen = be32(png + pos);
+		if ((size_t)clen > len - pos - 12) return E_HEADER;
+		if (!std::memcmp(png + pos + 4, "IHDR", 4)) { w = be32(png + pos + 8); h = be32(png + pos + 12); depth = png[pos + 16]; ctype = png[pos + 17]; interlace = png[pos + 20]; }
+		else if (!std::memcmp(png + pos + 4, "IDAT", 4)) idat.insert(idat.end(), png + pos + 8, png + pos + 8 + clen);
+		else if (!std::memcmp(png + pos + 4, "IEND", 4)) break;
+		pos += 12 + (size_t)clen;
+	}
+	if (!w || !h || depth != 8 || interlace) return E_HEADER;
+	const int bpp = ctype == 2 ? 3 : ctype == 6 ? 4 : (ctype == 0 || ctype == 3) ? 1 : 0;
+	if (!bpp) return E_HEADER;
+	*pw = w; *ph = h; *pbpp = (unsigned)bpp;
+	if (!unf) return 0;
+	if (cap < (size_t)w * h * bpp) return E_OUTSIZE;
+	std::vector<uint8_t> raw((size_t)h * ((size_t)w * bpp + 1));
+	int rc = inflate_model(idat.data(), idat.size(), raw.data(), (uint32_t)raw.size(), rcp_scale);
+	if (rc) return rc;
+	return unfilter_model(raw.data(), unf, (int)w, (int)h, bpp);
+}
+
+extern "C" void png_model_stats(unsigned long long* out) { for (int k = 0; k < 8; ++k) out[k] = g_stats[k]; }
+
+extern "C" int png_model_inflate(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect, float rcp_scale) { return inflate_model(zs, zlen, out, expect, rcp_scale); }
