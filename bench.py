@@ -284,6 +284,69 @@ def extras(dec, dev, stream, n, outs, steps):
                              "host_decode_cpu_s": round(tm["host_fill_s"], 3), "device_wait_s": round(tm["device_wait_s"], 4),
                              "note": "PNG files -> cimbar_ingest_run_files (read + inflate + un-filter on a host thread pool) -> the same ring"}
         ing.close()
+        # ---- the same files with the PNGs decoded ON THE DEVICE (cimbar_ingest_create_ex, CIMBAR_INGEST_PNG_DEVICE): the host threads only
+        # read the files and move their IDAT bytes; inflate + un-filter are kernels (one wavefront per image: large batches fill the GPU)
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for k in range(128):
+                pth = os.path.join(td, f"f{k:03d}.png")
+                Image.fromarray(host128[k]).save(pth, compress_level=1)
+                paths.append(pth)
+            mm = 8192
+            paths = paths * (mm // 128)
+            ing = ingest.Ingest(dec, threads=0, batch_frames=2048, ring=2, png_device=True, zbytes_per_frame=400000)
+            ing.run_files(paths[:256])
+            t0 = time.perf_counter()
+            total, chunks, masks = ing.run_files(paths)
+            dt = time.perf_counter() - t0
+            tm, ps = ing.timings(), ing.png_stats()
+            ing.close()
+            ok = total == mm * 7500 and bool((torch.from_numpy(chunks[:128]) == payload.cpu()).all()) and bool((torch.from_numpy(chunks[-128:]) == payload.cpu()).all())
+            out["ingest_png_device"] = {"files": mm, "ms": round(dt * 1e3, 3), "frames_per_s": round(mm / dt, 1), "payload_ok": ok,
+                                        "host_cpu_s": round(tm["host_fill_s"], 3), "device_wait_s": round(tm["device_wait_s"], 4),
+                                        "pcie_bytes_per_frame": int(ps["bytes_to_device"] / mm), "refused": ps["refused_by_host_walk"] + ps["refused_by_device"],
+                                        "note": "PNG files -> cimbar_ingest_run_files in device PNG mode: compressed bytes over PCIe, k_png_inflate + "
+                                                "k_png_unfilter + decode on the device (2 batches of 2048 in flight)"}
+            # the two PNG kernels alone on device-resident streams
+            from libcimbar_amd import decoder as _d
+            import ctypes as _ct
+            npng = 4096
+            desc = (_d.PngDesc * npng)()
+            blob, offs = bytearray(), []
+            for k in range(128):
+                w_, h_, ct_, _dp, _il, z, _pal = _d.png_split(open(paths[k], "rb").read())
+                while len(blob) % 16:
+                    blob.append(0)
+                offs.append((len(blob), len(z)))
+                blob += z
+            while len(blob) % 16:
+                blob.append(0)
+            for i in range(npng):
+                desc[i].zoff, desc[i].zlen = offs[i % 128]
+                desc[i].width, desc[i].height, desc[i].color_type = modeb.IMG, modeb.IMG, 2
+            d_z = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(dev)
+            d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
+            L = _d.load_library()
+            ss = int(L.cimbar_hip_png_scratch_bytes(modeb.IMG, modeb.IMG, 2))
+            d_scr = torch.empty(npng * ss, dtype=torch.uint8, device=dev)
+            d_rgb = torch.empty((npng, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+            d_st = torch.zeros(npng, dtype=torch.int32, device=dev)
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                L.cimbar_hip_png_decode_batch(dev.index, d_z.data_ptr(), d_z.numel(), d_desc.data_ptr(), npng, d_scr.data_ptr(), ss, d_rgb.data_ptr(),
+                                              modeb.FRAME_RGB_BYTES, d_st.data_ptr(), _ct.c_void_p(stream.cuda_stream))
+                torch.cuda.synchronize(dev)
+                dtk = time.perf_counter() - t0
+                best = dtk if best is None or dtk < best else best
+            fr128 = torch.from_numpy(host128).to(dev)
+            okk = bool((d_st == 0).all().item()) and all(bool((d_rgb[i] == fr128[i % 128]).all().item()) for i in range(0, npng, 61))
+            out["png_device_kernels"] = {"images": npng, "ms": round(best * 1e3, 2), "images_per_s": round(npng / best, 1), "pixels_ok": okk,
+                                         "avg_zlib_bytes": int(sum(l for _o, l in offs) / 128),
+                                         "note": "cimbar_hip_png_decode_batch on device-resident zlib streams of 1024x1024 frame PNGs (Pillow, compress_level 1): "
+                                                 "inflate (one wavefront per image, scalar-unit bound) + un-filter"}
+            del d_scr, d_rgb, fr128
     except Exception as e:
         out["ingest"] = {"error": repr(e)}
     # ---- modes 67 ("Bm", Conf8x8_mini: 1024x720 frames, 12 x 429 bytes), 66 ("Bu", Conf8x8_micro: 736x637, 6 x 540) and 4 (legacy 4-colour:
@@ -311,6 +374,10 @@ def extras(dec, dev, stream, n, outs, steps):
     try:
         from libcimbar_amd import extractbench
         out.update(extractbench.run(dec, dev, stream, synth))
+        torch.cuda.empty_cache()
+        # the same at 1024 captures per batch: the exact flood keeps one (two-wavefront) workgroup per frame busy for ~35 ms whatever the batch,
+        # so the per-batch time barely moves and throughput follows the batch size until every CU holds its four frames
+        out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=1, key="config5_extract_1024"))
     except ImportError:
         pass
     except Exception as e:

@@ -47,7 +47,7 @@ def make_captures(frames, width=1920, height=1080, background=24):
     return out
 
 
-def run(dec, dev, stream, synth, n=256, reps=3):
+def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract"):
     payload = framegen.synth_payload(n, seed=777, device=dev)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
     dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), stream.cuda_stream)
@@ -87,7 +87,7 @@ def run(dec, dev, stream, synth, n=256, reps=3):
     seen = info[info != 0xFFFFFFFF]
     rules = {str(int(r)): int(((seen & 0xFF) == r).sum()) for r in np.unique(seen & 0xFF)}
     declined = seen[(seen & 0xFF) != 0]
-    return {"config5_extract": {
+    return {key: {
         "captures": n, "size": [w, h], "ms": round(best_all * 1e3, 3), "captures_per_s": round(n / best_all, 1),
         "extract_only_ms": round(best_ext * 1e3, 3), "extract_only_captures_per_s": round(n / best_ext, 1),
         "extracted": int((st > 0).sum()), "needs_sharpen": int((st == 2).sum()), "frames_fully_decoded": int(full.sum()),

@@ -3,7 +3,8 @@
 // with its decompress_on_store writer -- the file appears in out_dir exactly as the reference CLI would write it.
 // Built in the build container against the reference headers (oracle/Makefile `dropin`), run on the GPU box by tests/test_gpu_ingest.py.
 //
-//   cimbar_amd_cli out_dir img1.png [img2.png ...]
+//   cimbar_amd_cli [--device-png] out_dir img1.png [img2.png ...]
+// --device-png: the PNGs are inflated and un-filtered on the GPU too (cimbar_ingest_create_ex, CIMBAR_INGEST_PNG_DEVICE)
 #include "cimb_translator/Config.h"
 #include "compression/zstd_decompressor.h"
 #include "fountain/fountain_decoder_sink.h"
@@ -34,12 +35,14 @@ int feed(void* user, const uint8_t* chunks, const uint32_t* masks, int first_fra
 
 int main(int argc, char** argv)
 {
-	if (argc < 3) { std::printf("usage: cimbar_amd_cli out_dir img1.png [img2.png ...]\n"); return 2; }
+	const bool device_png = argc > 1 && std::string(argv[1]) == "--device-png";
+	if (device_png) { ++argv; --argc; }
+	if (argc < 3) { std::printf("usage: cimbar_amd_cli [--device-png] out_dir img1.png [img2.png ...]\n"); return 2; }
 	cimbar::Config::update(68);
 	cimbar_hip_ctx* ctx = nullptr;
 	if (cimbar_hip_create(0, 68, &ctx) != 0) { std::printf("no device\n"); return 3; }
 	cimbar_ingest* ing = nullptr;
-	if (cimbar_ingest_create(ctx, 0, 16, 3, &ing) != 0) { std::printf("ingest create failed\n"); return 3; }
+	if (cimbar_ingest_create_ex(ctx, 0, device_png ? 256 : 16, 3, device_png ? CIMBAR_INGEST_PNG_DEVICE : CIMBAR_INGEST_PNG_HOST, 0, &ing) != 0) { std::printf("ingest create failed\n"); return 3; }
 	fountain_decoder_sink sink(cimbar::Config::fountain_chunk_size(), decompress_on_store<std::ofstream>(argv[1], true));
 	SinkState st{&sink};
 	const long long good = cimbar_ingest_run_files(ing, argv + 2, argc - 2, 0, 2, feed, &st);

@@ -13,8 +13,10 @@ from tests.frames import clean_frames
 pytestmark = pytest.mark.gpu
 
 
-def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder):
+@pytest.mark.parametrize("ring", ["32768", "8192"])     # the whole deflate window in LDS | an 8 KiB ring + far matches read back from global memory
+def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder, monkeypatch, ring):
     from libcimbar_amd import decoder, ingest
+    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
     _p, frames = clean_frames(synth, 1, seed=5151)
     cs = png_cases.cases(frames[0])
     got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs])
@@ -26,8 +28,10 @@ def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder):
         assert (ingest.png_decode(png) == img).all(), name
 
 
-def test_device_png_refuses_damaged_streams(hip_decoder):
+@pytest.mark.parametrize("ring", ["32768", "8192"])
+def test_device_png_refuses_damaged_streams(hip_decoder, monkeypatch, ring):
     from libcimbar_amd import decoder
+    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
     g = np.random.default_rng(3)
     im = g.integers(0, 256, (40, 30, 3), dtype=np.uint8)
     good = png_cases.make_png(im, [0] * 40)
@@ -39,9 +43,11 @@ def test_device_png_refuses_damaged_streams(hip_decoder):
     assert set(status[1:].tolist()) <= {decoder.PNG_ESTREAM, decoder.PNG_ECODES, decoder.PNG_ESIZE, decoder.PNG_ECHECK, decoder.PNG_EHEADER}
 
 
-def test_device_png_truncated_and_garbage_streams_terminate(hip_decoder):
+@pytest.mark.parametrize("ring", ["32768", "8192"])
+def test_device_png_truncated_and_garbage_streams_terminate(hip_decoder, monkeypatch, ring):
     """the kernel must come back with an error on streams that end early or are noise (never hang, never write outside its slot)"""
     import ctypes
+    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
     import torch
     from libcimbar_amd import decoder
     g = np.random.default_rng(5)

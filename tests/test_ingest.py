@@ -105,7 +105,8 @@ def test_ingest_pipeline_equals_batch_decode(tmp_path, synth, hip_decoder):
 
 
 @pytest.mark.gpu
-def test_cimbar_cli_shaped_program_decodes_config1_to_the_file(tmp_path, hip_decoder):
+@pytest.mark.parametrize("device_png", [False, True])       # PNG inflate + un-filter on the host pool | on the GPU
+def test_cimbar_cli_shaped_program_decodes_config1_to_the_file(tmp_path, hip_decoder, device_png):
     """BASELINE configs[0] end to end in C++: PNG file -> cimbar_amd_cli (ingest pool, device decode, the reference's sink + zstd writer,
     built against the reference headers) -> the file ./cimbar would have written"""
     exe = os.path.join(ROOT, "oracle", "_ref", "cimbar_amd_cli")
@@ -118,7 +119,7 @@ def test_cimbar_cli_shaped_program_decodes_config1_to_the_file(tmp_path, hip_dec
     Image.fromarray(frame).save(tmp_path / "frame_0.png")
     out_dir = tmp_path / "out"
     out_dir.mkdir()
-    res = subprocess.run([exe, str(out_dir), str(tmp_path / "frame_0.png")], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe] + (["--device-png"] if device_png else []) + [str(out_dir), str(tmp_path / "frame_0.png")], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     written = out_dir / fix["file"]
     assert written.exists(), (res.stdout, os.listdir(out_dir))

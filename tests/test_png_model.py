@@ -35,9 +35,11 @@ def decode(L, png, scale=1.0):
     return rc, out
 
 
+@pytest.mark.parametrize("ring", [32768, 8192])       # the two LDS ring sizes of k_png_inflate (8192: far matches come back from the flushed output)
 @pytest.mark.parametrize("scale", [1.0, 1.0 + 2e-7, 1.0 - 2e-7])   # the device's v_rcp_f32 is not exactly rounded: the j mod dist fix-up must absorb it
-def test_model_decodes_every_case(model, synth, scale):
+def test_model_decodes_every_case(model, synth, scale, ring):
     from tests.frames import clean_frames
+    model.png_model_ring(ring)
     _p, frames = clean_frames(synth, 1, seed=5151)
     for name, png, want in png_cases.cases(frames[0], big=(scale == 1.0)):
         rc, got = decode(model, png, scale)

@@ -11,10 +11,13 @@
 
 namespace {
 
-constexpr int WIN = 32768, WMASK = WIN - 1, FLUSH = 4096;
+constexpr int WIN = 32768;
+// the ring the device keeps in LDS: 32 KiB (the whole deflate window; flushed 4 KiB at a time) or 8 KiB (flushed 4 KiB at a time; a match from
+// further back than RING - 320 reads the bytes the flushes have already put into global memory). Set per call.
+int RING = 32768, WMASK = RING - 1, FLUSH = 4096;
 
 enum { PNG_OK = 0, E_BTYPE = -1, E_STORED = -2, E_OVERSUB = -3, E_INCOMPLETE = -4, E_CODE = -5, E_DIST = -6, E_OUTSIZE = -7, E_INPUT = -8, E_HEADER = -9, E_NOEOB = -10,
-       E_REPEAT = -11, E_FILTER = -12, E_ADLER = -13 };
+       E_REPEAT = -11, E_FILTER = -12, E_ADLER = -13, E_MODEL = -99 };
 
 struct Canon {           // what lane L (1..15) holds
 	uint32_t first[16];  // first code of length L
@@ -240,6 +243,11 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 				const float rcp = rcp_scale / (float)dist;
 				g_stats[1]++; g_stats[2] += len; if (dist < len) g_stats[5]++;
 				const uint32_t before = o.op;
+				if (dist > (uint32_t)RING - 320u) {
+					// far: every source byte has been flushed (op - flushed < FLUSH + 258, sources end below op - RING + 578) and dist >= len
+					if (before - dist + len > o.flushed || dist < len) return E_MODEL;
+					for (uint32_t j = 0; j < len; ++j) o.win[(before + j) & WMASK] = o.glob[before - dist + j];
+				} else
 				for (uint32_t c0 = 0; c0 < len; c0 += 64) {
 					uint8_t tmp[64];
 					const uint32_t m = len - c0 < 64 ? len - c0 : 64;
@@ -323,6 +331,8 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 }  // namespace
 
 // PNG (8-bit gray / RGB / RGBA / palette, non-interlaced) -> un-filtered samples (h*w*bpp); returns 0 or a negative code; *pw,*ph,*pbpp set
+extern "C" void png_model_ring(int ring) { RING = ring; WMASK = ring - 1; FLUSH = ring >= 32768 ? 4096 : ring / 2; }
+
 extern "C" int png_model_decode(const uint8_t* png, size_t len, uint8_t* unf, size_t cap, unsigned* pw, unsigned* ph, unsigned* pbpp, float rcp_scale)
 {
 	if (len < 33 || std::memcmp(png, "\x89PNG\r\n\x1a\n", 8) != 0) return E_HEADER;
