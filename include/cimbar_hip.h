@@ -204,7 +204,8 @@ int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int roo
  * A batch of PNG images whose zlib streams (the concatenated IDAT payloads) already sit in device memory -> dense RGB8 frames in device
  * memory, without the decoded pixels ever crossing PCIe: inflate (one wavefront per image, Huffman decode + LZ77 window in LDS, Adler-32
  * checked) and the scanline un-filter (rows skewed over the lanes). 8 bits per sample, non-interlaced, colour types 0 (gray, replicated),
- * 2 (RGB), 3 (palette), 6 (RGBA, alpha dropped) -- what cv::imread(IMREAD_COLOR) + BGR2RGB gives. Context-free: `device` is a HIP ordinal.
+ * 2 (RGB), 3 (palette), 6 (RGBA, alpha dropped) -- what cv::imread(IMREAD_COLOR) + BGR2RGB gives; at most 2048 pixels wide (frames are
+ * 1024 or 736). Context-free: `device` is a HIP ordinal.
  *   d_zbuf / zbuf_bytes : the streams (and palettes), device memory
  *   d_desc              : n descriptors, device memory
  *   d_scratch           : n * scratch_stride bytes for the filtered scanlines; scratch_stride >= cimbar_hip_png_scratch_bytes(), multiple of 16

@@ -1,5 +1,5 @@
 """Device PNG decode timings (gpurun): the two kernels over a batch of frame PNGs, and the ingest library's device mode against its host mode.
-    python tools/png_bench.py [n_images] [n_files]"""
+    python tools/png_bench.py [n_images] [n_files] [levels, e.g. 1,6]"""
 import ctypes, io, json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +18,8 @@ dec.encode_batch_device(payload.data_ptr(), 128, fr.data_ptr())
 torch.cuda.synchronize()
 host128 = fr.cpu().numpy()
 out = {}
-for lvl, n in ((1, n), (6, n), (1, 4 * n)):
+levels = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,6").split(",")]
+for lvl, n in [(l, n) for l in levels] + [(1, 4 * n)]:
     pngs = []
     for k in range(128):
         buf = io.BytesIO()
