@@ -222,7 +222,7 @@ enum {
 };
 typedef struct cimbar_hip_png_desc {
 	uint64_t zoff;        /* byte offset of the image's zlib stream in d_zbuf, a multiple of 16 */
-	uint32_t zlen;        /* its length */
+	uint32_t zlen;        /* its length, below 256 MiB (bit positions are 32-bit) */
 	uint32_t width, height;
 	uint32_t color_type;  /* 0, 2, 3, 6 */
 	uint32_t pal_off;     /* colour type 3: byte offset in d_zbuf of 256 RGB palette entries (768 bytes) */

@@ -150,3 +150,35 @@ def corrupt_cases(seed=11):
     out.append(("btype3", bytes(b)))
     out.append(("truncated", good[:i + n // 2] + good[i + n:]))
     return out
+
+
+def fuzz_cases(n, seed):
+    """n random small PNGs: random size, content (noise / runs / tiles / gradients / mixtures), colour type, per-row filters and deflate
+    parameters (level, strategy, window, memLevel, IDAT split): (name, png, expected RGB)"""
+    g = np.random.default_rng(seed)
+    out = []
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    for i in range(n):
+        h, w = int(g.integers(1, 150)), int(g.integers(1, 260))
+        bpp = int(g.choice([1, 3, 3, 3, 4]))
+        kind = int(g.integers(0, 5))
+        if kind == 0:
+            im = g.integers(0, 256, (h, w, bpp), dtype=np.uint8)
+        elif kind == 1:
+            im = np.full((h, w, bpp), int(g.integers(0, 256)), np.uint8)
+            im[g.integers(0, h, 5), :, :] = g.integers(0, 256, (5, 1, bpp), dtype=np.uint8)
+        elif kind == 2:
+            t = g.integers(0, 256, (int(g.integers(1, 12)), int(g.integers(1, 12)), bpp), dtype=np.uint8)
+            im = np.tile(t, (h // t.shape[0] + 1, w // t.shape[1] + 1, 1))[:h, :w]
+        elif kind == 3:
+            im = ((np.add.outer(np.arange(h) * int(g.integers(1, 5)), np.arange(w) * int(g.integers(1, 5))) % 256).astype(np.uint8))[..., None].repeat(bpp, 2)
+        else:
+            im = np.where(g.random((h, w, 1)) < 0.1, g.integers(0, 256, (h, w, bpp), dtype=np.uint8), np.uint8(int(g.integers(0, 256)))).astype(np.uint8)
+        im = np.ascontiguousarray(im)
+        ctype, pal = {1: 0, 3: 2, 4: 6}[bpp], None
+        if bpp == 1 and g.random() < 0.5:
+            ctype, pal = 3, g.integers(0, 256, (256, 3), dtype=np.uint8)
+        png = make_png(im, g.integers(0, 5, h), level=int(g.integers(0, 10)), strategy=strategies[int(g.integers(0, 5))], wbits=int(g.integers(9, 16)),
+                       mem=int(g.integers(1, 10)), ctype=ctype, palette=pal, idat_split=int(g.choice([0, 0, 100, 8192])))
+        out.append((f"fuzz{seed}_{i}_{h}x{w}x{bpp}_k{kind}" + ("_pal" if ctype == 3 else ""), png, to_rgb(im, ctype, pal)))
+    return out

@@ -29,6 +29,19 @@ def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder, mon
 
 
 @pytest.mark.parametrize("ring", ["32768", "8192"])
+def test_device_png_fuzz(hip_decoder, monkeypatch, ring):
+    """600 random small PNGs (size, content, colour type, per-row filters, deflate level / strategy / window / memLevel, IDAT split) in one batch"""
+    from libcimbar_amd import decoder
+    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
+    cs = png_cases.fuzz_cases(600, seed=int(ring))
+    got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs])
+    bad = [(name, int(st)) for (name, _p, _w), st in zip(cs, status) if st != 0]
+    assert not bad, bad[:10]
+    wrong = [name for (name, _p, want), img in zip(cs, got) if img.shape != want.shape or not (img == want).all()]
+    assert not wrong, wrong[:10]
+
+
+@pytest.mark.parametrize("ring", ["32768", "8192"])
 def test_device_png_refuses_damaged_streams(hip_decoder, monkeypatch, ring):
     from libcimbar_amd import decoder
     monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)

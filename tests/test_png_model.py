@@ -54,3 +54,15 @@ def test_model_refuses_damaged_streams(model):
     for name, png in png_cases.corrupt_cases():
         rc, _ = decode(model, png)
         assert rc != 0, name
+
+
+@pytest.mark.parametrize("ring", [32768, 8192])
+def test_model_fuzz(model, ring):
+    model.png_model_ring(ring)
+    for name, png, want in png_cases.fuzz_cases(150, seed=ring):
+        rc, got = decode(model, png)
+        assert rc == 0, (name, rc)
+        if name.endswith("_pal"):
+            continue                     # a palette image: the model stops at the indices
+        rgb = got if got.shape[2] == 3 else got[..., :3] if got.shape[2] == 4 else np.repeat(got, 3, axis=2)
+        assert (rgb == want).all(), name
