@@ -292,9 +292,9 @@ def extras(dec, dev, stream, n, outs, steps):
                 pth = os.path.join(td, f"f{k:03d}.png")
                 Image.fromarray(host128[k]).save(pth, compress_level=1)
                 paths.append(pth)
-            mm = 16384
+            mm = 32768
             paths = paths * (mm // 128)
-            ing = ingest.Ingest(dec, threads=0, batch_frames=2048, ring=3, png_device=True, zbytes_per_frame=400000)
+            ing = ingest.Ingest(dec, threads=0, batch_frames=4096, ring=3, png_device=True, zbytes_per_frame=360000)
             ing.run_files(paths[:256])
             t0 = time.perf_counter()
             total, chunks, masks = ing.run_files(paths)
@@ -306,11 +306,11 @@ def extras(dec, dev, stream, n, outs, steps):
                                         "host_cpu_s": round(tm["host_fill_s"], 3), "device_wait_s": round(tm["device_wait_s"], 4),
                                         "pcie_bytes_per_frame": int(ps["bytes_to_device"] / mm), "refused": ps["refused_by_host_walk"] + ps["refused_by_device"],
                                         "note": "PNG files -> cimbar_ingest_run_files in device PNG mode: compressed bytes over PCIe, k_png_inflate + "
-                                                "k_png_unfilter + decode on the device (up to 3 batches of 2048 in flight)"}
+                                                "k_png_unfilter + decode on the device (up to 3 batches of 4096 in flight: the four-streams-per-wavefront inflate)"}
             # the two PNG kernels alone on device-resident streams
             from libcimbar_amd import decoder as _d
             import ctypes as _ct
-            npng = 4096
+            npng = 8192
             desc = (_d.PngDesc * npng)()
             blob, offs = bytearray(), []
             for k in range(128):
@@ -345,7 +345,7 @@ def extras(dec, dev, stream, n, outs, steps):
             out["png_device_kernels"] = {"images": npng, "ms": round(best * 1e3, 2), "images_per_s": round(npng / best, 1), "pixels_ok": okk,
                                          "avg_zlib_bytes": int(sum(l for _o, l in offs) / 128),
                                          "note": "cimbar_hip_png_decode_batch on device-resident zlib streams of 1024x1024 frame PNGs (Pillow, compress_level 1): "
-                                                 "inflate (one wavefront per image, scalar-unit bound) + un-filter"}
+                                                 "inflate (four streams per wavefront at this size) + un-filter"}
             del d_scr, d_rgb, fr128
     except Exception as e:
         out["ingest"] = {"error": repr(e)}

@@ -327,7 +327,9 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			if (e == hipSuccess) e = hipEventRecord(sl.copied, ing->copy_stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(sl.png_stream, sl.copied, 0);
 			if (e != hipSuccess) { ing->err = std::string("copy of the PNG streams: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
-			r = cimbar_hip_png_decode_batch(ing->device, sl.d_z, ing->zcap, sl.d_desc, m, sl.d_scratch, ing->scratch_stride, sl.d_in, ing->frame, sl.d_status, sl.png_stream);
+			// (R batches are kept in flight: with 8192+ images among them the four-streams-per-wavefront inflate is the faster one)
+			r = cimbar_hip_png_decode_batch_v(ing->device, sl.d_z, ing->zcap, sl.d_desc, m, sl.d_scratch, ing->scratch_stride, sl.d_in, ing->frame, sl.d_status,
+			                                  (long)B * R >= 8192 ? 4 : 0, sl.png_stream);
 			if (r != 0) { ing->err = "cimbar_hip_png_decode_batch failed to launch"; rc = r; break; }
 			r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, sl.png_stream);
 		} else {

@@ -28,7 +28,7 @@ EXPORTS = (
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
     "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
-    "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch",
+    "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
 )
 PNG_EHEADER, PNG_ESTREAM, PNG_ECODES, PNG_ESIZE, PNG_ECHECK = -30, -31, -32, -33, -34
 
@@ -119,6 +119,8 @@ def load_library(path=None):
     lib.cimbar_hip_png_scratch_bytes.restype = sz
     lib.cimbar_hip_png_decode_batch.argtypes = [i32, vp, sz, vp, i32, vp, sz, vp, sz, vp, vp]
     lib.cimbar_hip_png_decode_batch.restype = i32
+    lib.cimbar_hip_png_decode_batch_v.argtypes = [i32, vp, sz, vp, i32, vp, sz, vp, sz, vp, i32, vp]
+    lib.cimbar_hip_png_decode_batch_v.restype = i32
     if path is None:
         _lib = lib
     return lib

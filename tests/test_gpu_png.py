@@ -12,11 +12,23 @@ from tests.frames import clean_frames
 
 pytestmark = pytest.mark.gpu
 
+# the inflate kernel's variants: one stream per wavefront with the whole deflate window in LDS | with an 8 KiB ring + far matches read back from
+# global memory; four streams per wavefront (sixteen lanes each) with a 2 KiB | 4 KiB ring
+VARIANTS = ["32768", "8192", "simt2048", "simt4096"]
 
-@pytest.mark.parametrize("ring", ["32768", "8192"])     # the whole deflate window in LDS | an 8 KiB ring + far matches read back from global memory
+
+def select(monkeypatch, variant):
+    if variant.startswith("simt"):
+        monkeypatch.setenv("CIMBAR_HIP_PNG_SIMT", variant[4:])
+    else:
+        monkeypatch.setenv("CIMBAR_HIP_PNG_SIMT", "0")
+        monkeypatch.setenv("CIMBAR_HIP_PNG_RING", variant)
+
+
+@pytest.mark.parametrize("ring", VARIANTS)
 def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder, monkeypatch, ring):
     from libcimbar_amd import decoder, ingest
-    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
+    select(monkeypatch, ring)
     _p, frames = clean_frames(synth, 1, seed=5151)
     cs = png_cases.cases(frames[0])
     got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs])
@@ -28,12 +40,12 @@ def test_device_png_equals_known_pixels_and_host_decoder(synth, hip_decoder, mon
         assert (ingest.png_decode(png) == img).all(), name
 
 
-@pytest.mark.parametrize("ring", ["32768", "8192"])
+@pytest.mark.parametrize("ring", VARIANTS)
 def test_device_png_fuzz(hip_decoder, monkeypatch, ring):
     """600 random small PNGs (size, content, colour type, per-row filters, deflate level / strategy / window / memLevel, IDAT split) in one batch"""
     from libcimbar_amd import decoder
-    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
-    cs = png_cases.fuzz_cases(600, seed=int(ring))
+    select(monkeypatch, ring)
+    cs = png_cases.fuzz_cases(600, seed=sum(map(ord, ring)))
     got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs])
     bad = [(name, int(st)) for (name, _p, _w), st in zip(cs, status) if st != 0]
     assert not bad, bad[:10]
@@ -41,10 +53,10 @@ def test_device_png_fuzz(hip_decoder, monkeypatch, ring):
     assert not wrong, wrong[:10]
 
 
-@pytest.mark.parametrize("ring", ["32768", "8192"])
+@pytest.mark.parametrize("ring", VARIANTS)
 def test_device_png_refuses_damaged_streams(hip_decoder, monkeypatch, ring):
     from libcimbar_amd import decoder
-    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
+    select(monkeypatch, ring)
     g = np.random.default_rng(3)
     im = g.integers(0, 256, (40, 30, 3), dtype=np.uint8)
     good = png_cases.make_png(im, [0] * 40)
@@ -56,11 +68,11 @@ def test_device_png_refuses_damaged_streams(hip_decoder, monkeypatch, ring):
     assert set(status[1:].tolist()) <= {decoder.PNG_ESTREAM, decoder.PNG_ECODES, decoder.PNG_ESIZE, decoder.PNG_ECHECK, decoder.PNG_EHEADER}
 
 
-@pytest.mark.parametrize("ring", ["32768", "8192"])
+@pytest.mark.parametrize("ring", VARIANTS)
 def test_device_png_truncated_and_garbage_streams_terminate(hip_decoder, monkeypatch, ring):
     """the kernel must come back with an error on streams that end early or are noise (never hang, never write outside its slot)"""
     import ctypes
-    monkeypatch.setenv("CIMBAR_HIP_PNG_RING", ring)
+    select(monkeypatch, ring)
     import torch
     from libcimbar_amd import decoder
     g = np.random.default_rng(5)

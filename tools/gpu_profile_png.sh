@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + two PMC passes of the device PNG decode (tools/png_bench.py, kernels only:
-# 1024 level-1 frame PNGs with the 32 KiB ring, 4096 with the 8 KiB ring). Usage: tools/gpu_profile_png.sh <tag>
+# 2048 level-1 frame PNGs with one stream per wavefront and the 8 KiB ring, 8192 with four streams per wavefront). Usage: tools/gpu_profile_png.sh <tag>
 TAG=${1:-png}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/tools/png_bench.py 1024 0 1"
+CMD="python $R/tools/png_bench.py 2048 0 1"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

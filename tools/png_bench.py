@@ -8,7 +8,7 @@ from PIL import Image
 from libcimbar_amd import HipDecoder, decoder, framegen, ingest, modeb
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-nfiles = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+nfiles = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 dev = torch.device("cuda", 0)
 dec = HipDecoder(0)
 lib = decoder.load_library()
@@ -19,6 +19,7 @@ torch.cuda.synchronize()
 host128 = fr.cpu().numpy()
 out = {}
 levels = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,6").split(",")]
+variant = os.environ.get("CIMBAR_HIP_PNG_SIMT", "0")
 for lvl, n in [(l, n) for l in levels] + [(1, 4 * n)]:
     pngs = []
     for k in range(128):
@@ -56,7 +57,7 @@ for lvl, n in [(l, n) for l in levels] + [(1, 4 * n)]:
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     ok = bool((d_status == 0).all().item()) and all(bool((d_rgb[i] == fr[i % 128]).all().item()) for i in range(0, n, 37))
-    out[f"kernels_level{lvl}_n{n}"] = {"images": n, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1), "ok": ok, "rc": rc,
+    out[f"kernels_level{lvl}_n{n}"] = {"simt": variant, "images": n, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1), "ok": ok, "rc": rc,
                                   "avg_zlib_bytes": int(sum(l for _o, l in offs) / 128)}
     print(json.dumps(out[f"kernels_level{lvl}_n{n}"]), flush=True)
     del d_scratch, d_rgb
@@ -70,7 +71,7 @@ with tempfile.TemporaryDirectory() as td:
           Image.fromarray(host128[k]).save(pth, compress_level=1)
           paths.append(pth)
       paths = (paths * ((nfiles + 127) // 128))[:nfiles]
-      for label, kw in (("device_b2048", dict(batch_frames=2048, ring=2, png_device=True, zbytes_per_frame=400000)), ("device_b512", dict(batch_frames=512, ring=3, png_device=True)),
+      for label, kw in (("device_b4096r3", dict(batch_frames=4096, ring=3, png_device=True, zbytes_per_frame=360000)), ("device_b2048r3", dict(batch_frames=2048, ring=3, png_device=True, zbytes_per_frame=400000)),
                         ("host_b64", dict(batch_frames=64, ring=3))):
           ing = ingest.Ingest(dec, threads=0, **kw)
           ing.run_files(paths[:min(kw["batch_frames"], 256)])
