@@ -35,10 +35,16 @@ def decode(L, png, scale=1.0):
     return rc, out
 
 
-@pytest.mark.parametrize("ring", [32768, 8192])       # the two LDS ring sizes of k_png_inflate (8192: far matches come back from the flushed output)
+# (input chunk model, LDS ring): a plain dword stream | k_png_inflate's 64-dword chunks with the whole window or the 8 KiB ring (far matches come
+# back from the flushed output) | k_png_inflate4's 16-dword chunks per row with 2 KiB / 4 KiB rings
+KERNELS = [(0, 32768), (64, 32768), (64, 8192), (16, 2048), (16, 4096)]
+
+
+@pytest.mark.parametrize("chunk,ring", KERNELS)
 @pytest.mark.parametrize("scale", [1.0, 1.0 + 2e-7, 1.0 - 2e-7])   # the device's v_rcp_f32 is not exactly rounded: the j mod dist fix-up must absorb it
-def test_model_decodes_every_case(model, synth, scale, ring):
+def test_model_decodes_every_case(model, synth, scale, chunk, ring):
     from tests.frames import clean_frames
+    model.png_model_chunk(chunk)
     model.png_model_ring(ring)
     _p, frames = clean_frames(synth, 1, seed=5151)
     for name, png, want in png_cases.cases(frames[0], big=(scale == 1.0)):
@@ -51,15 +57,18 @@ def test_model_decodes_every_case(model, synth, scale, ring):
 
 
 def test_model_refuses_damaged_streams(model):
+    model.png_model_chunk(0)
+    model.png_model_ring(32768)
     for name, png in png_cases.corrupt_cases():
         rc, _ = decode(model, png)
         assert rc != 0, name
 
 
-@pytest.mark.parametrize("ring", [32768, 8192])
-def test_model_fuzz(model, ring):
+@pytest.mark.parametrize("chunk,ring", KERNELS[1:])
+def test_model_fuzz(model, chunk, ring):
+    model.png_model_chunk(chunk)
     model.png_model_ring(ring)
-    for name, png, want in png_cases.fuzz_cases(150, seed=ring):
+    for name, png, want in png_cases.fuzz_cases(150, seed=ring + chunk):
         rc, got = decode(model, png)
         assert rc == 0, (name, rc)
         if name.endswith("_pal"):

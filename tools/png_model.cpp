@@ -1,6 +1,6 @@
 // png_model.cpp -- CPU model of the DEVICE PNG decoder's algorithm (csrc/png.hip.inc), statement for statement where the arithmetic matters:
-// lane-parallel canonical Huffman decode (per-length first / count / base), the 64-dword input chunks and the refill rule, the 32 KiB ring
-// with 4 KiB flushes, the periodic overlapped copy (float reciprocal + correction for j mod dist) and the skewed (one row per lane) un-filter.
+// lane-parallel canonical Huffman decode (per-length first / count / base), the lane-parallel input chunks (64 dwords per wavefront, or 16 per
+// row of lanes) with their overlap / switch rules and the per-token 64-bit window, the LDS ring (32 / 8 / 4 / 2 KiB) with its flushes and far reads, the periodic overlapped copy (float reciprocal + correction for j mod dist) and the skewed (one row per lane) un-filter.
 // Development aid: built by tests/test_png_model.py with g++ and fuzzed against zlib / Pillow on the CPU, so that what is left to find on
 // the GPU is plumbing, not arithmetic. Not part of the product and not an oracle for the decode path.
 //   g++ -O2 -shared -fPIC -o /tmp/libpng_model.so tools/png_model.cpp
@@ -55,17 +55,83 @@ int canon_build(Canon& c, const uint8_t* lengths, int n, bool is_codes)
 	return PNG_OK;
 }
 
+// The device reads its input through lane-parallel chunks: 64 dwords per wavefront (k_png_inflate: lane i holds dword cbase + i; the next
+// chunk starts 60 further on and is switched to at k >= 62 by the bit buffer, at (bp >> 5) - cbase >= 60 by the symbol loop's 64-bit window)
+// or 16 dwords per row of lanes (k_png_inflate4: step 12, window-only). CHUNK = 0 models none of that (plain dword stream), 64 / 16 model
+// the chunk bookkeeping as well and fail with E_MODEL whenever an access would leave the lanes of the current chunk.
+int CHUNK = 0;
+bool g_chunk_fault = false;
+
 struct BitReader {
 	const uint32_t* in;     // the stream, dword-aligned start
 	size_t nwords, widx;
 	uint64_t bb;
 	int nb;
 	bool overrun;
-	uint32_t next_dword() { if (widx >= nwords) { if (widx > nwords + 2) overrun = true; ++widx; return 0; } return in[widx++]; }
-	void refill() { if (nb <= 32) { bb |= (uint64_t)next_dword() << nb; nb += 32; } }      // afterwards nb >= 33: a caller may take up to 32 bits
-	uint32_t peek(int n) const { return (uint32_t)(bb & ((1ull << n) - 1ull)); }
-	void drop(int n) { bb >>= n; nb -= n; }
+	// chunk model
+	uint32_t cbase = 0, bp = 0;
+	bool insym = false;          // inside a block's symbol loop: one chunk check + one 64-bit window per token, fields come out of that window
+	uint64_t Rtok = 0;
+	uint32_t tokbase = 0;
+	void begin_symbols() { if (CHUNK) { if (CHUNK == 64) bp = bitpos(); insym = true; } }
+	void end_symbols() { if (insym) { insym = false; if (CHUNK == 64) seat_bit(bp); } }
+	void token() { if (insym) { ensure_window(bp); Rtok = window(bp); tokbase = bp; } else refill(); }
+	uint32_t at(size_t i) const { return i < nwords ? in[i] : 0u; }
+	uint32_t lane_of(size_t i, int lanes)          // dword i out of the current chunk
+	{
+		if (i < cbase || i - cbase >= (size_t)lanes) { g_chunk_fault = true; return 0; }
+		return at(i);
+	}
+	uint32_t next_dword()
+	{
+		if (widx > nwords + 2) overrun = true;
+		if (CHUNK == 64) {
+			if (widx - cbase >= 62) cbase += 60;                 // ensure(): cur = nxt
+			const uint32_t v = lane_of(widx, 64);
+			++widx;
+			return v;
+		}
+		return at(widx++);
+	}
+	uint64_t window(uint32_t p)                     // the 64 bits at bit position p (three lanes of the current chunk)
+	{
+		const size_t kk = p >> 5;
+		const uint32_t sh = p & 31u, lanes = CHUNK == 16 ? 16 : 64;
+		const uint32_t d0 = lane_of(kk, lanes), d1 = lane_of(kk + 1, lanes), d2 = lane_of(kk + 2, lanes);
+		const uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh), hi = (uint32_t)((((uint64_t)d2 << 32) | d1) >> sh);
+		return ((uint64_t)hi << 32) | lo;
+	}
+	void ensure_window(uint32_t p)                  // the symbol loop's (and Bits4's) chunk check
+	{
+		const uint32_t step = CHUNK == 16 ? 12 : 60;
+		if ((p >> 5) - cbase >= step) cbase += step;
+	}
+	void refill() { if (!insym && CHUNK != 16 && nb <= 32) { bb |= (uint64_t)next_dword() << nb; nb += 32; } }      // afterwards nb >= 33: a caller may take up to 32 bits
+	uint32_t peek(int n)
+	{
+		if (insym) { const uint32_t sh = bp - tokbase; if (sh + (uint32_t)n > 64u) g_chunk_fault = true; return (uint32_t)(Rtok >> (sh & 63u)) & ((1u << n) - 1u); }
+		if (CHUNK == 16) { ensure_window(bp); return (uint32_t)window(bp) & ((1u << n) - 1u); }
+		return (uint32_t)(bb & ((1ull << n) - 1ull));
+	}
+	void drop(int n) { if (insym || CHUNK == 16) { bp += (uint32_t)n; if ((bp >> 5) > nwords + 2) overrun = true; } else { bb >>= n; nb -= n; } }
 	uint32_t get(int n) { const uint32_t v = peek(n); drop(n); return v; }
+	void align() { if (CHUNK == 16) bp = (bp + 7u) & ~7u; else drop(nb & 7); }
+	size_t bytepos() const { return CHUNK == 16 ? (size_t)(bp >> 3) : widx * 4 - (size_t)(nb / 8); }
+	void seat_byte(size_t np)                       // continue at byte np of the stream (after a stored block)
+	{
+		if (CHUNK == 16) { bp = (uint32_t)(np * 8); cbase = bp >> 5; return; }
+		widx = np / 4; cbase = (uint32_t)widx; bb = 0; nb = 0;
+		refill();
+		drop((int)(8 * (np % 4)));
+	}
+	uint32_t bitpos() const { return CHUNK == 16 ? bp : (uint32_t)(widx * 32 - (size_t)nb); }
+	void seat_bit(uint32_t p)                       // the symbol loop hands the position back to the bit buffer
+	{
+		if (CHUNK == 16) { bp = p; return; }
+		widx = p >> 5; bb = 0; nb = 0;
+		refill();
+		drop((int)(p & 31u));
+	}
 };
 
 uint32_t rev15(uint32_t v)   // bit-reverse the low 15 bits (the device: v_bfrev_b32 >> 17)
@@ -139,6 +205,7 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 	std::vector<uint32_t> words((zlen + 3) / 4 + 1, 0);
 	std::memcpy(words.data(), zs, zlen);
 	BitReader br{words.data(), (zlen + 3) / 4, 0, 0, 0, false};
+	g_chunk_fault = false;
 	br.refill();
 	br.drop(16);                                  // CMF, FLG
 	static Out o;
@@ -152,14 +219,14 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 		if (btype == 3) return E_BTYPE;
 		g_stats[3]++; if (btype == 2) g_stats[6]++;
 		if (btype == 0) {
-			br.drop(br.nb & 7);
+			br.align();
 			br.refill();
 			const uint32_t len = br.get(16);
 			br.refill();
 			const uint32_t nlen = br.get(16);
 			if ((len ^ nlen) != 0xFFFFu) return E_STORED;
 			// the bytes follow at byte position 4 * widx - nb / 8 of the stream
-			const size_t bpos = br.widx * 4 - (size_t)(br.nb / 8);
+			const size_t bpos = br.bytepos();
 			if (bpos + len > zlen) return E_INPUT;
 			if (o.op + len > o.cap) return E_OUTSIZE;
 			g_stats[4] += len;
@@ -169,10 +236,7 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 				o.op += m;
 				o.after(before);
 			}
-			const size_t np = bpos + len;
-			br.widx = np / 4; br.bb = 0; br.nb = 0;
-			br.refill();
-			br.drop((int)(8 * (np % 4)));
+			br.seat_byte(bpos + len);
 		} else {
 			if (btype == 1) {
 				for (int s = 0; s < 144; ++s) lengths[s] = 8;
@@ -215,8 +279,9 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 				rc = canon_build(dd, lengths + hlit, hdist, false);
 				if (rc) return rc;
 			}
+			br.begin_symbols();
 			for (;;) {
-				br.refill();
+				br.token();
 				int sym;
 				int rc = canon_decode(ll, br, &sym);
 				if (rc) return rc;
@@ -229,7 +294,7 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 					o.after(before);
 					continue;
 				}
-				if (sym == 256) break;
+				if (sym == 256) { br.end_symbols(); break; }
 				if (sym > 285) return E_CODE;
 				const uint32_t len = LBASE[sym - 257] + br.get(LEXT[sym - 257]);   // <= 15 + 5 bits since the refill
 				br.refill();
@@ -264,13 +329,15 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 		if (bfinal) break;
 	}
 	if (br.overrun) return E_INPUT;
+	if (g_chunk_fault) return E_MODEL;
 	o.flush_to(o.op);
 	if (o.op != expect) return E_OUTSIZE;
 	// the Adler-32 of the inflated bytes follows the last block at the next byte boundary, big-endian (RFC 1950)
-	br.drop(br.nb & 7);
+	br.align();
 	uint32_t want = 0;
 	for (int k = 0; k < 4; ++k) { br.refill(); want = (want << 8) | br.get(8); }
 	if (br.overrun) return E_INPUT;
+	if (g_chunk_fault) return E_MODEL;
 	return want == ((o.a2 << 16) | o.a1) ? PNG_OK : E_ADLER;
 }
 
@@ -331,6 +398,8 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 }  // namespace
 
 // PNG (8-bit gray / RGB / RGBA / palette, non-interlaced) -> un-filtered samples (h*w*bpp); returns 0 or a negative code; *pw,*ph,*pbpp set
+extern "C" void png_model_chunk(int chunk) { CHUNK = chunk; }
+
 extern "C" void png_model_ring(int ring) { RING = ring; WMASK = ring - 1; FLUSH = ring >= 32768 ? 4096 : ring / 2; }
 
 extern "C" int png_model_decode(const uint8_t* png, size_t len, uint8_t* unf, size_t cap, unsigned* pw, unsigned* ph, unsigned* pbpp, float rcp_scale)
