@@ -109,11 +109,13 @@ def test_device_png_truncated_and_garbage_streams_terminate(hip_decoder, monkeyp
     assert (d_scratch[n * ss:] == 0xA5).all() and (d_rgb[n * rs:] == 0x5A).all()
 
 
-def test_ingest_device_png_mode_equals_host_mode(tmp_path, synth, hip_decoder):
+@pytest.mark.parametrize("simt", ["0", "2048"])       # the inflate kernel the ingest's device mode ends up with: one | four streams per wavefront
+def test_ingest_device_png_mode_equals_host_mode(tmp_path, synth, hip_decoder, monkeypatch, simt):
     """files -> libcimbar_ingest.so in device PNG mode (compressed bytes over PCIe, inflate + un-filter on the GPU) == its host mode == the
     payload; unreadable / damaged / wrong-size / 16-bit files deliver nothing in both"""
     from PIL import Image
     from libcimbar_amd import ingest
+    monkeypatch.setenv("CIMBAR_HIP_PNG_SIMT", simt)
     payload, frames = clean_frames(synth, 12, seed=909)
     paths = []
     for k in range(12):
