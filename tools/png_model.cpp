@@ -393,6 +393,79 @@ int unfilter_model(const uint8_t* raw, uint8_t* unf, int w, int h, int bpp)
 	return PNG_OK;
 }
 
+
+// the device's fast path (unfilter_image4, widths that are a multiple of 4): the same skew in units of four pixels, with the device's byte
+// arithmetic -- Sub / Up / Average on all channels of a dword at once, Paeth on two 16-bit lanes per register -- restated operation for operation
+inline uint32_t add_bytes(uint32_t x, uint32_t y) { return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u); }
+inline uint32_t avg_bytes(uint32_t x, uint32_t y) { return (x & y) + (((x ^ y) & 0xfefefefeu) >> 1); }
+inline uint32_t paeth_packed(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t out = 0;
+	for (int h = 0; h < 2; ++h) {
+		// bytes (2h, 2h + 1) as two 16-bit lanes
+		int16_t A[2], B[2], C[2], P[2];
+		for (int k = 0; k < 2; ++k) { A[k] = (int16_t)((a >> (8 * (2 * h + k))) & 255u); B[k] = (int16_t)((b >> (8 * (2 * h + k))) & 255u); C[k] = (int16_t)((c >> (8 * (2 * h + k))) & 255u); }
+		for (int k = 0; k < 2; ++k) {
+			const int16_t d1 = (int16_t)(B[k] - C[k]), d2 = (int16_t)(A[k] - C[k]), d3 = (int16_t)(d1 + d2);
+			const int16_t pa = d1 > (int16_t)-d1 ? d1 : (int16_t)-d1, pb = d2 > (int16_t)-d2 ? d2 : (int16_t)-d2, pc = d3 > (int16_t)-d3 ? d3 : (int16_t)-d3;
+			const uint16_t n1 = (uint16_t)((int16_t)(pb - pa) >> 15), n2 = (uint16_t)((int16_t)(pc - pa) >> 15), n3 = (uint16_t)((int16_t)(pc - pb) >> 15);
+			const uint16_t m = n1 | n2, bc = (uint16_t)(((uint16_t)B[k] & ~n3) | ((uint16_t)C[k] & n3));
+			P[k] = (int16_t)(((uint16_t)A[k] & ~m) | (bc & m));
+		}
+		out |= ((uint32_t)(P[0] & 255) << (8 * (2 * h))) | ((uint32_t)(P[1] & 255) << (8 * (2 * h + 1)));
+	}
+	return out;
+}
+
+int unfilter_model4(const uint8_t* raw, uint8_t* unf, int w, int h, int bpp)
+{
+	const int rb = w * bpp, nblk = w / 4;
+	const uint32_t pmask = bpp == 4 ? 0xFFFFFFFFu : (1u << (8 * bpp)) - 1u;
+	std::vector<uint32_t> boundary((size_t)w, 0);
+	for (int band = 0; band * 64 < h; ++band) {
+		uint32_t po[64][4], a[64], upprev3[64];
+		for (int l = 0; l < 64; ++l) { a[l] = upprev3[l] = 0; for (int k = 0; k < 4; ++k) po[l][k] = 0; }
+		bool any_paeth = false;
+		for (int l = 0; l < 64; ++l) if (band * 64 + l < h && raw[(size_t)(band * 64 + l) * (rb + 1)] == 4) any_paeth = true;
+		for (int T = 0; T < nblk + 63; ++T) {
+			uint32_t npo[64][4], nup3[64];
+			std::vector<std::pair<int, uint32_t>> bwrites;
+			for (int l = 0; l < 64; ++l) {
+				const int row = band * 64 + l, q = T - l;
+				const bool rowok = row < h, active = rowok && q >= 0 && q < nblk;
+				uint32_t up[4];
+				for (int k = 0; k < 4; ++k) up[k] = l > 0 ? po[l - 1][k] : 0u;          // wave_shr:1 of last step's outputs
+				if (l == 0 && band > 0 && q < nblk) for (int k = 0; k < 4; ++k) up[k] = boundary[(size_t)4 * q + k];
+				const uint32_t ft = rowok ? raw[(size_t)row * (rb + 1)] : 0u;
+				if (ft > 4) return E_FILTER;
+				for (int k = 0; k < 4; ++k) {
+					uint32_t f = 0;
+					if (active) for (int ch = 0; ch < bpp; ++ch) f |= (uint32_t)raw[(size_t)row * (rb + 1) + 1 + ((size_t)4 * q + k) * bpp + ch] << (8 * ch);
+					const uint32_t b = up[k], c = k == 0 ? upprev3[l] : up[k - 1];
+					uint32_t pred = 0;
+					pred = ft == 1u ? a[l] : pred;
+					pred = ft == 2u ? b : pred;
+					pred = ft == 3u ? avg_bytes(a[l], b) : pred;
+					if (any_paeth && ft == 4u) {
+						if (bpp < 3) { pred = 0; for (int ch = 0; ch < bpp; ++ch) pred |= (uint32_t)paeth((int)((a[l] >> (8 * ch)) & 255u), (int)((b >> (8 * ch)) & 255u), (int)((c >> (8 * ch)) & 255u)) << (8 * ch); }
+						else pred = paeth_packed(a[l], b, c);
+					}
+					uint32_t o = add_bytes(f, pred) & pmask;
+					o = active ? o : 0u;
+					a[l] = o;
+					npo[l][k] = o;
+					if (active) for (int ch = 0; ch < bpp; ++ch) unf[((size_t)row * w + 4 * q + k) * bpp + ch] = (uint8_t)(o >> (8 * ch));
+					if (active && l == 63) bwrites.emplace_back(4 * q + k, o);
+				}
+				nup3[l] = up[3];
+			}
+			for (int l = 0; l < 64; ++l) { upprev3[l] = nup3[l]; for (int k = 0; k < 4; ++k) po[l][k] = npo[l][k]; }
+			for (auto& bw : bwrites) boundary[(size_t)bw.first] = bw.second;
+		}
+	}
+	return PNG_OK;
+}
+
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 }  // namespace
@@ -425,7 +498,7 @@ extern "C" int png_model_decode(const uint8_t* png, size_t len, uint8_t* unf, si
 	std::vector<uint8_t> raw((size_t)h * ((size_t)w * bpp + 1));
 	int rc = inflate_model(idat.data(), idat.size(), raw.data(), (uint32_t)raw.size(), rcp_scale);
 	if (rc) return rc;
-	return unfilter_model(raw.data(), unf, (int)w, (int)h, bpp);
+	return (w % 4 == 0) ? unfilter_model4(raw.data(), unf, (int)w, (int)h, bpp) : unfilter_model(raw.data(), unf, (int)w, (int)h, bpp);
 }
 
 extern "C" void png_model_stats(unsigned long long* out) { for (int k = 0; k < 8; ++k) out[k] = g_stats[k]; }
