@@ -29,7 +29,11 @@ extern "C" {
 #define CIMBAR_HIP_CELLS 12400             /* GridConf.h:42-45 */
 #define CIMBAR_HIP_CHUNK_SIZE 625          /* Config::fountain_chunk_size(), GridConf.h:63-71 */
 #define CIMBAR_HIP_CHUNKS_PER_FRAME 12     /* Config::fountain_chunks_per_frame(6), GridConf.h:54-61 */
-#define CIMBAR_HIP_FRAME_BYTES (CIMBAR_HIP_CHUNK_SIZE * CIMBAR_HIP_CHUNKS_PER_FRAME) /* 7500 = cimbard_get_bufsize() */
+#define CIMBAR_HIP_FRAME_BYTES (CIMBAR_HIP_CHUNK_SIZE * CIMBAR_HIP_CHUNKS_PER_FRAME) /* 7500 = cimbard_get_bufsize() in mode B -- MODE B ONLY */
+/* The largest chunk space any mode's frame needs: mode 8 (the legacy 8-colour mode) delivers 10 chunks of 875 bytes = 8750 (modes 68 / 4:
+ * 7500, 67: 5148, 66: 3240). Size fixed buffers with THIS, or ask cimbar_hip_ctx_bufsize(ctx) -- never with CIMBAR_HIP_FRAME_BYTES unless the
+ * context is known to be mode B's. */
+#define CIMBAR_HIP_MAX_FRAME_BYTES 8750
 
 enum {
 	CIMBAR_HIP_OK = 0,
@@ -49,15 +53,20 @@ typedef struct cimbar_hip_ctx cimbar_hip_ctx;
  * 1024x1024, GridConf.h:121-142; 0 selects it too, Config::temp_conf's default), 67 ("Bm", Conf8x8_mini, 1024x720, GridConf.h:168-189) and
  * 66 ("Bu", Conf8x8_micro, 736x637, GridConf.h:144-166), and 4 (the legacy 4-colour mode, Config.h:24-29: mode B's grid with the coupled decode
  * of Decoder.h:121-161 -- one Reed-Solomon stream of 6-bit cells, the old palette, no header-derived colour correction) and 8 (the legacy
- * 8-colour mode, Config.h:30-35: 7-bit cells, 70 blocks, 10 * 875 bytes) -- every mode Config::temp_conf knows. Any other value ->
- * CIMBAR_HIP_EINVAL. `device` is a HIP device ordinal. Everywhere below "frame" means an
+ * 8-colour mode, Config.h:30-35: 7-bit cells, 70 blocks, 10 * 875 bytes) -- every mode Config::temp_conf knows. Any other value selects mode
+ * 68, exactly like Config::temp_conf's `default:` branch (Config.h:41-43): cimbard_configure_decode(5) upstream gives a working mode-B
+ * decoder, and so does cimbar_hip_create(dev, 5) (cimbar_hip_geometry then reports mode 68). `device` is a HIP device ordinal. Everywhere below "frame" means an
  * image_size_x x image_size_y RGB8 image of the context's mode, "12 * 625" the mode's chunks-per-frame * chunk size (12 * 429 in mode 67,
  * 6 * 540 in mode 66, 10 * 750 in mode 4; the mask has as many bits) and "60 blocks of 125" its RS layout (36 of 143; 24 of 135):
  * cimbar_hip_geometry reports the numbers. */
 int cimbar_hip_create(int device, int mode_val, cimbar_hip_ctx** out);
 void cimbar_hip_destroy(cimbar_hip_ctx* ctx);
 
-/* cimbard_get_bufsize(): bytes of chunk space one frame needs in the DEFAULT mode (12 * 625); a context's own is geometry[4] * geometry[5] */
+/* cimbard_get_bufsize() (cimbar_recv_js.cpp:143-146) = fountain_chunks_per_frame() * fountain_chunk_size() of the ACTIVE configuration. The
+ * reference's configuration is a thread_local; here it lives in the context, so the faithful counterpart takes one:
+ *   cimbar_hip_ctx_bufsize(ctx) : the chunk space one frame of THIS context needs (7500 / 5148 / 3240 / 7500 / 8750 for modes 68 / 67 / 66 / 4 / 8)
+ *   cimbar_hip_bufsize()        : the same for the default configuration (mode B, what a thread that never called Config::update has): 7500 */
+int cimbar_hip_ctx_bufsize(const cimbar_hip_ctx* ctx);
 int cimbar_hip_bufsize(void);
 
 /* The grid a context was created for -- the Config:: getters the reference's callers size their buffers with (Config.h:52-165):
@@ -78,7 +87,8 @@ const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
 
 /* Decoder::decode_fountain(img, sink, should_preprocess, color_correction) for ONE host-resident frame.
  *   rgb        : height rows of `stride` bytes, width*3 used (RGB8, as cv::Mat CV_8UC3 after BGR2RGB, cimbar.cpp:132-133)
- *   chunks     : 12*625 bytes; slot j holds fountain chunk j of the frame, zero-filled if the chunk was dropped
+ *   chunks     : cimbar_hip_ctx_bufsize(ctx) bytes (12*625 in mode B; at most CIMBAR_HIP_MAX_FRAME_BYTES); slot j holds fountain chunk j of the
+ *                frame, zero-filled if the chunk was dropped
  *   good_mask  : bit j set <=> aligned_stream delivered chunk j to the sink (aligned_stream.h:62-85)
  * Returns the reference's return value: cumulative good bytes = 625 * popcount(mask) (Decoder.h:116-117).
  * Image size, as CimbReader's constructor treats it (CimbReader.cpp:107-126):
@@ -132,6 +142,10 @@ int64_t cimbar_hip_decode_plain_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, i
 int cimbar_hip_reset_ccm(cimbar_hip_ctx* ctx);
 /* Current carried CCM, row-major 3x3; returns 1 if active, 0 if not (CimbDecoder::get_ccm, CimbDecoder.cpp:76-80). */
 int cimbar_hip_get_ccm(cimbar_hip_ctx* ctx, float out9[9]);
+/* CimbDecoder::update_color_correction (CimbDecoder.cpp:82-85; what DecoderPlus::load_ccm feeds from `--color-correction-file`,
+ * DecoderPlus.h:32-45, cimbar.cpp:265-266): the carried matrix becomes m9 (row-major 3x3) and is active from the next frame on, until a frame
+ * derives its own (color_correction 2 with a decoded header) or cimbar_hip_reset_ccm. Waits for batches in flight. */
+int cimbar_hip_set_ccm(cimbar_hip_ctx* ctx, const float m9[9]);
 
 /* ---- the encode half ("next" row of the scope table: on-device frame synthesiser) --------------------------------------------
  * Encoder::encode_next (src/lib/encoder/Encoder.h:69-129) for n frames at once: each frame takes 7500 payload bytes (the 60
@@ -148,9 +162,10 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
  * The reference turns a camera capture into the decoder's 1024x1024 frame with Extractor::extract (src/lib/extractor/Extractor.h:29-45):
  * Scanner (gray -> small Gaussian -> Otsu threshold, Scanner.h:148-165; then a sparse scan-line search for the four anchors on that
  * binary image, Scanner.h:277-405) and Deskewer::deskew (cv::getPerspectiveTransform + cv::warpPerspective INTER_LINEAR,
- * Deskewer.h:26-40). The two image passes are here; the anchor search stays host code on the binary image this returns (2 MB per
- * 1080p capture instead of 6 MB), and its four corners come back for the warp, whose output can stay in device memory for
- * cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated, see DESIGN.md.
+ * Deskewer.h:26-40). These two calls are the image passes on their own (a caller with its own anchor search, or the adapter's
+ * cimbar_amd::Deskewer); the whole of Extractor::extract, anchor search included, is cimbar_hip_extract_batch below. The warp's output can
+ * stay in device memory for cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated,
+ * see DESIGN.md.
  *   cimbar_hip_scan_preprocess : n captures -> n * width * height bytes (0 / 255) = Scanner::preprocess_image(img, fast = true);
  *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Blur unit as in Scanner.h:157-159 (3x3 below 1500 px on the short side, 5x5 below 2500, 9x9 below 4500); 4500 px and more: EDIM.
  *   cimbar_hip_deskew_batch    : corners = n * 8 floats in HOST memory, per capture top-left, top-right, bottom-left, bottom-right (x, y)
@@ -206,7 +221,8 @@ int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int roo
  * checked) and the scanline un-filter (rows skewed over the lanes). 8 bits per sample, non-interlaced, colour types 0 (gray, replicated),
  * 2 (RGB), 3 (palette), 6 (RGBA, alpha dropped) -- what cv::imread(IMREAD_COLOR) + BGR2RGB gives; at most 2048 pixels wide (frames are
  * 1024 or 736). Context-free: `device` is a HIP ordinal.
- *   d_zbuf / zbuf_bytes : the streams (and palettes), device memory
+ *   d_zbuf / zbuf_bytes : the streams (and palettes), device memory. The kernels read whole dwords: every stream's end rounded up to a multiple
+ *                         of 4 must lie inside zbuf_bytes (checked; an image whose padded end does not is refused with EHEADER)
  *   d_desc              : n descriptors, device memory
  *   d_scratch           : n * scratch_stride bytes for the filtered scanlines; scratch_stride >= cimbar_hip_png_scratch_bytes(), multiple of 16
  *   d_rgb               : n * rgb_stride bytes; image i's width*height*3 bytes start at i * rgb_stride
@@ -247,9 +263,13 @@ enum {
 	CIMBAR_HIP_TAP_FLOOD = 5,      /* n bytes         : 1 = frame needed the exact flood-order pass */
 	CIMBAR_HIP_TAP_CCM = 6,        /* n * 10 floats   : 3x3 matrix used for the colour pass + active flag */
 	CIMBAR_HIP_TAP_FLOOD_PATH = 7, /* n bytes         : 0 = parallel pass was exact, 1 = exact flood replay, 2 = certified batch flood */
-	CIMBAR_HIP_TAP_FLOOD_INFO = 8  /* n u32           : what the batch-parallel flood made of a flagged frame: low byte 0 = certified, 1..4 = the rule
+	CIMBAR_HIP_TAP_FLOOD_INFO = 8, /* n u32           : what the batch-parallel flood made of a flagged frame: low byte 0 = certified, 1..4 = the rule
 	                                  that declined it, 5 = out of super-rounds; bits 8..15 the super-round; bits 16.. cells decoded by then.
 	                                  0xFFFFFFFF for frames that were never flagged */
+	CIMBAR_HIP_TAP_FLOOD_VERIFY = 9 /* n u32          : with CIMBAR_HIP_FLOOD_VERIFY=1 in the environment at cimbar_hip_create, every frame the batch-parallel
+	                                  flood certified is ALSO replayed exactly and compared: cells whose symbol or drifted position differed
+	                                  (0 = the certificate held; the exact result is what the decode used either way); 0xFFFFFFFF for frames
+	                                  that were not certified, or when the mode is off. The context prints the totals to stderr at destroy. */
 };
 int64_t cimbar_hip_tap(cimbar_hip_ctx* ctx, int what, void* out, size_t out_bytes);
 

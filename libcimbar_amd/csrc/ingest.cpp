@@ -159,7 +159,7 @@ int png_walk(const uint8_t* png, size_t len, PngInfo& info)
 		pos += 12 + (size_t)clen;
 	}
 	if (!have_ihdr || info.w == 0 || info.h == 0 || depth != 8 || interlace != 0) return CIMBAR_INGEST_EFORMAT;
-	if (!(info.ctype == 0 || info.ctype == 2 || info.ctype == 3 || info.ctype == 6) || info.zlen < 6 || info.zlen > 0xFFFFFFF0u) return CIMBAR_INGEST_EFORMAT;
+	if (!(info.ctype == 0 || info.ctype == 2 || info.ctype == 3 || info.ctype == 6) || info.zlen < 6 || info.zlen >= (1u << 28)) return CIMBAR_INGEST_EFORMAT;   // the device kernels' bit positions are 32-bit: streams below 256 MiB (cimbar_hip.h)
 	if (info.ctype == 3 && !info.plte) return CIMBAR_INGEST_EFORMAT;
 	return 0;
 }
@@ -357,7 +357,11 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 		if (c < 0) rc = c;
 		else if (c > 0) rc = 1;
 	}
-	stop.store(true);
+	{
+		// under the mutex: a worker that has just found its wait predicate false must not miss this wake-up (it would sleep for ever and join() hang)
+		std::lock_guard<std::mutex> lk(mu);
+		stop.store(true);
+	}
 	cv.notify_all();
 	for (auto& t : pool) t.join();
 	(void)hipStreamSynchronize(ing->copy_stream);
@@ -431,6 +435,7 @@ int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, 
 		// tenth); a file that does not fit any more is skipped like one that cannot be read
 		const size_t per = zbytes_per_frame ? zbytes_per_frame : ing->frame / 4;
 		ing->zcap = ((size_t)ing->B * per + 4095) & ~(size_t)4095;
+		if (ing->zcap > 0xFFFFF000ull) return fail("batch_frames * zbytes_per_frame exceeds 4 GiB (cimbar_hip_png_desc::pal_off is 32-bit)");
 		ing->scratch_stride = cimbar_hip_png_scratch_bytes(ing->fw, ing->fh, 6);     // RGBA is the widest form a frame can arrive in
 	}
 	for (auto& s : ing->slots) {

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM, TAP_FLOOD_PATH, TAP_FLOOD_INFO = range(9)
+TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM, TAP_FLOOD_PATH, TAP_FLOOD_INFO, TAP_FLOOD_VERIFY = range(10)
 
 # every symbol include/cimbar_hip.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
 EXPORTS = (
@@ -29,6 +29,7 @@ EXPORTS = (
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
     "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
     "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
+    "cimbar_hip_ctx_bufsize", "cimbar_hip_set_ccm",
 )
 PNG_EHEADER, PNG_ESTREAM, PNG_ECODES, PNG_ESIZE, PNG_ECHECK = -30, -31, -32, -33, -34
 
@@ -105,6 +106,10 @@ def load_library(path=None):
     lib.cimbar_hip_reset_ccm.restype = i32
     lib.cimbar_hip_get_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.cimbar_hip_get_ccm.restype = i32
+    lib.cimbar_hip_set_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.cimbar_hip_set_ccm.restype = i32
+    lib.cimbar_hip_ctx_bufsize.argtypes = [vp]
+    lib.cimbar_hip_ctx_bufsize.restype = i32
     lib.cimbar_hip_tap.argtypes = [vp, i32, vp, sz]
     lib.cimbar_hip_tap.restype = i64
     lib.cimbar_hip_enable_timing.argtypes = [vp, i32]
@@ -446,11 +451,20 @@ class HipDecoder:
         rc = self._check(self._lib.cimbar_hip_get_ccm(self._ctx, out), "cimbar_hip_get_ccm")
         return bool(rc), np.array(list(out), dtype=np.float32).reshape(3, 3)
 
+    def set_ccm(self, m):
+        """CimbDecoder::update_color_correction: the carried matrix becomes `m` (3x3) and is active from the next frame on"""
+        arr = (ctypes.c_float * 9)(*[float(x) for x in np.asarray(m, dtype=np.float32).reshape(-1)])
+        self._check(self._lib.cimbar_hip_set_ccm(self._ctx, arr), "cimbar_hip_set_ccm")
+
+    def bufsize(self):
+        """cimbard_get_bufsize() of this context's configuration"""
+        return self._check(self._lib.cimbar_hip_ctx_bufsize(self._ctx), "cimbar_hip_ctx_bufsize")
+
     def tap(self, what, n):
         shapes = {
             TAP_BITPLANE: ((n, self.geo.IMG_W * self.geo.IMG_H // 8), np.uint8), TAP_SYMBOLS: ((n, self.geo.NCELLS), np.uint8),
             TAP_COLORS: ((n, self.geo.NCELLS), np.uint8), TAP_DRIFT: ((n, self.geo.NCELLS, 2), np.int8),
-            TAP_RS_OK: ((n, self.geo.BLOCKS), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8), TAP_FLOOD_INFO: ((n,), np.uint32),
+            TAP_RS_OK: ((n, self.geo.BLOCKS), np.uint8), TAP_FLOOD: ((n,), np.uint8), TAP_CCM: ((n, 10), np.float32), TAP_FLOOD_PATH: ((n,), np.uint8), TAP_FLOOD_INFO: ((n,), np.uint32), TAP_FLOOD_VERIFY: ((n,), np.uint32),
         }
         shape, dt = shapes[what]
         out = np.zeros(shape, dtype=dt)

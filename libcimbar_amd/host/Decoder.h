@@ -15,12 +15,20 @@
 //     class Extractor          src/lib/extractor/Extractor.h:11-45 cimbar_amd::Extractor        (extract(img, out) -> FAILURE / SUCCESS / NEEDS_SHARPEN, the
 //                                                                                               anchor search included, on the device)
 //
+//     class DecoderPlus        src/lib/encoder/DecoderPlus.h:11-58 cimbar_amd::Decoder::load_ccm / save_ccm (`--color-correction-file`, cimbar.cpp:265-266,297-298)
+//
 // Header-only; link against libcimbar_hip.so. No exceptions, no OpenCV requirement: MAT is anything shaped like cv::Mat
-// (`data`, `cols`, `rows`, `step`), e.g. cv::Mat, cv::UMat::getMat(), or cimbar_amd::image_view below.
+// (`data`, `cols`, `rows`, `step`), e.g. cv::Mat or cimbar_amd::image_view below -- or anything with a `getMat(access)` member that
+// returns such a thing: cv::UMat as it is, which is what ./cimbar hands to decode_fountain and Extractor::extract (cimbar.cpp:132,146,167-171;
+// CimbReader.h:16-17 has the same pair of constructors).
 #pragma once
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/cimbar_hip.h"
@@ -43,17 +51,55 @@ struct PositionData   // src/lib/cimb_translator/PositionData.h
 	int y = 0;
 };
 
+// cv::UMat and friends: `img.getMat(cv::ACCESS_READ)` without naming OpenCV. The access argument's type is taken from the member's own
+// signature (an enum in OpenCV 4, an int in OpenCV 3) and its value is ACCESS_READ = 1 << 24 in both (core/mat.hpp, enum AccessFlag).
+namespace detail {
+template <typename T> struct getmat_arg;
+template <typename C, typename R, typename A> struct getmat_arg<R (C::*)(A) const> { typedef A type; };
+template <typename T, typename = void> struct has_getmat : std::false_type {};
+template <typename T> struct has_getmat<T, decltype(void(&T::getMat))> : std::true_type {};
+
+// `use(m)` is called with something that has data / cols / rows / step: `img` itself, or the cv::Mat header img.getMat(ACCESS_READ) returns
+// (alive for the duration of the call, like the temporary in CimbReader's UMat constructor, CimbReader.cpp:128-131). Tag dispatch, so that
+// `use` is only ever instantiated with the type it will really see.
+template <typename MAT, typename F>
+auto with_mat_impl(const MAT& img, F&& use, std::false_type) { return use(img); }
+template <typename MAT, typename F>
+auto with_mat_impl(const MAT& img, F&& use, std::true_type)
+{
+	typedef typename getmat_arg<decltype(&MAT::getMat)>::type access_t;
+	const auto m = img.getMat(static_cast<access_t>(1 << 24));
+	return use(m);
+}
+template <typename MAT, typename F>
+auto with_mat(const MAT& img, F&& use) { return with_mat_impl(img, std::forward<F>(use), has_getmat<MAT>()); }
+// the same for an image that is written: getMat(ACCESS_RW = 3 << 24) maps the UMat's buffer, the header's destructor unmaps it
+template <typename MAT, typename F>
+void with_mat_rw_impl(MAT& img, F&& use, std::false_type) { use(img); }
+template <typename MAT, typename F>
+void with_mat_rw_impl(MAT& img, F&& use, std::true_type)
+{
+	typedef typename getmat_arg<decltype(&MAT::getMat)>::type access_t;
+	auto m = img.getMat(static_cast<access_t>(3 << 24));
+	use(m);
+}
+template <typename MAT, typename F>
+void with_mat_rw(MAT& img, F&& use) { with_mat_rw_impl(img, std::forward<F>(use), has_getmat<MAT>()); }
+}  // namespace detail
+
 class Decoder
 {
 public:
-	// Decoder(use_ecc, interleave) as in Decoder.h:40-45. Only the reference's defaults (ECC on, interleave on) exist on the GPU path, in the
-	// modes cimbar_hip_create builds (68 "B", 67 "Bm" -- what cimbard_configure_decode / Config::update(mode_val) selects in the reference);
-	// anything else leaves the object !good() and every decode returns 0, like a reference decode that found nothing.
+	// Decoder(use_ecc, interleave) as in Decoder.h:40-45. Only the reference's defaults (ECC on, interleave on) exist on the GPU path, in every
+	// mode Config::temp_conf lists (68 "B", 67 "Bm", 66 "Bu", the legacy 4 and 8; any other value is mode B there and here, Config.h:41-43) --
+	// what cimbard_configure_decode / Config::update(mode_val) selects in the reference. ECC or interleave off leaves the object !good() and
+	// every decode returns 0, like a reference decode that found nothing.
 	explicit Decoder(bool use_ecc = true, bool interleave = true, int device = 0, int mode_val = 68)
 	{
 		if (use_ecc && interleave) _rc = cimbar_hip_create(device, mode_val, &_ctx);
 		else _rc = CIMBAR_HIP_EINVAL;
 		if (_ctx && cimbar_hip_geometry(_ctx, _geo) != CIMBAR_HIP_GEOMETRY_WORDS) { cimbar_hip_destroy(_ctx); _ctx = nullptr; _rc = CIMBAR_HIP_EHIP; }
+		if (_ctx) _frame.resize((size_t)cimbar_hip_ctx_bufsize(_ctx));   // one frame's chunk space, by the CONTEXT's mode (8750 bytes in mode 8)
 	}
 	~Decoder() { if (_ctx) cimbar_hip_destroy(_ctx); }
 	Decoder(const Decoder&) = delete;
@@ -64,8 +110,9 @@ public:
 	const char* last_error() const { return cimbar_hip_last_error(_ctx); }
 	cimbar_hip_ctx* context() { return _ctx; }
 
-	// the Config:: getters of the context's mode (Config.h:52-165). The CIMBAR_HIP_* macros of cimbar_hip.h are mode B's values, the largest
-	// of the built modes, so buffers sized with them hold either.
+	// the Config:: getters of the context's mode (Config.h:52-165). The CIMBAR_HIP_CHUNK_SIZE / _FRAME_BYTES macros of cimbar_hip.h are mode
+	// B's values and NOT the largest (mode 8: 10 x 875 = 8750 bytes): size by frame_bytes() / cimbar_hip_ctx_bufsize, or CIMBAR_HIP_MAX_FRAME_BYTES.
+	int mode() const { return (int)_geo[0]; }
 	unsigned image_size_x() const { return (unsigned)_geo[1]; }
 	unsigned image_size_y() const { return (unsigned)_geo[2]; }
 	unsigned total_cells() const { return (unsigned)_geo[3]; }
@@ -75,6 +122,33 @@ public:
 	unsigned cells_per_col_x() const { return (unsigned)_geo[9]; }
 	unsigned cells_per_col_y() const { return (unsigned)_geo[10]; }
 	unsigned cell_offset() const { return (unsigned)_geo[11]; }
+	unsigned symbol_bits() const { return 4; }                                       // every 8x8 configuration (GridConf.h:126,149,173)
+	unsigned color_bits() const { return mode() == 8 ? 3u : 2u; }                    // Config.h:24-35
+	unsigned color_mode() const { return (mode() == 4 || mode() == 8) ? 0u : 1u; }   // Config::color_mode(): legacy_mode ? 0 : 1 (Config.h:61-64)
+
+	// DecoderPlus::load_ccm / save_ccm (DecoderPlus.h:32-58): a file of nine floats, row-major 3x3 -- `./cimbar --color-correction-file`
+	// loads it before a --no-fountain decode and saves the matrix in force after a fountain decode (cimbar.cpp:265-266,297-298).
+	bool update_color_correction(const float m9[9]) { return _ctx && (_rc = cimbar_hip_set_ccm(_ctx, m9)) == 0; }   // CimbDecoder::update_color_correction
+	bool load_ccm(const std::string& filename)
+	{
+		float m[9];
+		FILE* f = std::fopen(filename.c_str(), "rb");
+		if (!f) return false;
+		const size_t got = std::fread(m, 1, sizeof m, f);
+		std::fclose(f);
+		if (got < sizeof m) return false;            // `data.size() < 3*3*4` (DecoderPlus.h:36-37)
+		return update_color_correction(m);
+	}
+	bool save_ccm(const std::string& filename)
+	{
+		float m[9];
+		if (!_ctx || cimbar_hip_get_ccm(_ctx, m) != 1) return false;   // `not get_ccm().active()` (DecoderPlus.h:49-50)
+		FILE* f = std::fopen(filename.c_str(), "wb");
+		if (!f) return false;
+		const size_t put = std::fwrite(m, 1, sizeof m, f);
+		std::fclose(f);
+		return put == sizeof m;
+	}
 
 	// Decoder::decode_fountain (Decoder.h:171-189): good chunks reach ostream.write(buf, 625) in chunk order, exactly what
 	// aligned_stream would have delivered; returns the cumulative good bytes. A sink whose chunk_size() is not 625 receives
@@ -82,19 +156,7 @@ public:
 	template <typename MAT, typename FOUNTAINSTREAM>
 	unsigned decode_fountain(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess = false, int color_correction = 2)
 	{
-		if (!_ctx) return 0;
-		unsigned char chunks[CIMBAR_HIP_FRAME_BYTES];
-		uint32_t mask = 0;
-		const size_t step = image_step(img);
-		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
-		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
-		_rc = res < 0 ? res : 0;
-		if (res <= 0) return 0;   // CimbReader::_good == false / nothing decoded
-		const unsigned cs = fountain_chunk_size();
-		if (ostream.chunk_size() == cs)
-			for (unsigned j = 0; j < fountain_chunks_per_frame(); ++j)
-				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * cs, cs);
-		return (unsigned)res;
+		return detail::with_mat(img, [&](const auto& m) { return decode_fountain_mat(m, ostream, should_preprocess, color_correction); });
 	}
 
 	// Decoder::decode (Decoder.h:163-169), the `--no-fountain` path (cimbar.cpp:270-272): the frame's 60 Reed-Solomon outputs go to
@@ -103,30 +165,7 @@ public:
 	template <typename MAT, typename STREAM>
 	unsigned decode(const MAT& img, STREAM& ostream, bool should_preprocess = false, int color_correction = 2)
 	{
-		if (!_ctx) return 0;
-		if ((unsigned)img.cols < image_size_x() || (unsigned)img.rows < image_size_y()) {
-			// CimbReader::_good == false (CimbReader.cpp:119): the reference writes its all-zero Reed-Solomon outputs
-			const std::vector<char> z(frame_bytes(), 0);
-			ostream.write(z.data(), frame_bytes());
-			return (unsigned)ostream.tellp();
-		}
-		if ((unsigned)img.cols != image_size_x() || (unsigned)img.rows != image_size_y()) { _rc = CIMBAR_HIP_EDIM; return 0; }   // (padded images: decode_fountain only)
-		std::vector<unsigned char> packed;
-		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
-		const size_t step = image_step(img), dense = (size_t)image_size_x() * 3;
-		if (step != dense) {
-			packed.resize(dense * image_size_y());
-			for (int y = 0; y < (int)image_size_y(); ++y)
-				for (size_t k = 0; k < dense; ++k) packed[(size_t)y * dense + k] = src[(size_t)y * step + k];
-			src = packed.data();
-		}
-		unsigned char bytes[CIMBAR_HIP_FRAME_BYTES];
-		int64_t res = cimbar_hip_decode_plain_batch(_ctx, src, 1, CIMBAR_HIP_MEM_HOST, should_preprocess ? 1 : 0, color_correction, bytes, nullptr,
-		                                            CIMBAR_HIP_MEM_HOST, nullptr);
-		_rc = res < 0 ? (int)res : 0;
-		if (res <= 0) return 0;
-		ostream.write(reinterpret_cast<const char*>(bytes), frame_bytes());
-		return (unsigned)ostream.tellp();
+		return detail::with_mat(img, [&](const auto& m) { return decode_mat(m, ostream, should_preprocess, color_correction); });
 	}
 
 	// n densely packed image_size_x x image_size_y RGB8 frames in host memory, decoded on the GPU in one batch; chunks go to the sink in frame
@@ -153,6 +192,53 @@ public:
 	const std::vector<uint32_t>& last_masks() const { return _masks; }
 
 protected:
+	template <typename MAT, typename FOUNTAINSTREAM>
+	unsigned decode_fountain_mat(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess, int color_correction)
+	{
+		if (!_ctx) return 0;
+		unsigned char* chunks = _frame.data();   // frame_bytes() of the context's mode
+		uint32_t mask = 0;
+		const size_t step = image_step(img);
+		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
+		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
+		_rc = res < 0 ? res : 0;
+		if (res <= 0) return 0;   // CimbReader::_good == false / nothing decoded
+		const unsigned cs = fountain_chunk_size();
+		if (ostream.chunk_size() == cs)
+			for (unsigned j = 0; j < fountain_chunks_per_frame(); ++j)
+				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * cs, cs);
+		return (unsigned)res;
+	}
+
+	template <typename MAT, typename STREAM>
+	unsigned decode_mat(const MAT& img, STREAM& ostream, bool should_preprocess, int color_correction)
+	{
+		if (!_ctx) return 0;
+		if ((unsigned)img.cols < image_size_x() || (unsigned)img.rows < image_size_y()) {
+			// CimbReader::_good == false (CimbReader.cpp:119): the reference writes its all-zero Reed-Solomon outputs
+			const std::vector<char> z(frame_bytes(), 0);
+			ostream.write(z.data(), frame_bytes());
+			return (unsigned)ostream.tellp();
+		}
+		if ((unsigned)img.cols != image_size_x() || (unsigned)img.rows != image_size_y()) { _rc = CIMBAR_HIP_EDIM; return 0; }   // (padded images: decode_fountain only)
+		std::vector<unsigned char> packed;
+		const unsigned char* src = reinterpret_cast<const unsigned char*>(img.data);
+		const size_t step = image_step(img), dense = (size_t)image_size_x() * 3;
+		if (step != dense) {
+			packed.resize(dense * image_size_y());
+			for (int y = 0; y < (int)image_size_y(); ++y)
+				for (size_t k = 0; k < dense; ++k) packed[(size_t)y * dense + k] = src[(size_t)y * step + k];
+			src = packed.data();
+		}
+		unsigned char* bytes = _frame.data();   // frame_bytes() of the context's mode
+		int64_t res = cimbar_hip_decode_plain_batch(_ctx, src, 1, CIMBAR_HIP_MEM_HOST, should_preprocess ? 1 : 0, color_correction, bytes, nullptr,
+		                                            CIMBAR_HIP_MEM_HOST, nullptr);
+		_rc = res < 0 ? (int)res : 0;
+		if (res <= 0) return 0;
+		ostream.write(reinterpret_cast<const char*>(bytes), frame_bytes());
+		return (unsigned)ostream.tellp();
+	}
+
 	template <typename MAT>
 	static size_t image_step(const MAT& img)
 	{
@@ -163,6 +249,7 @@ protected:
 	cimbar_hip_ctx* _ctx = nullptr;
 	int _rc = 0;
 	int32_t _geo[CIMBAR_HIP_GEOMETRY_WORDS] = {};
+	std::vector<unsigned char> _frame;    // one frame's chunk space (cimbar_hip_ctx_bufsize)
 	std::vector<unsigned char> _chunks;
 	std::vector<uint32_t> _masks;
 };
@@ -172,12 +259,13 @@ protected:
 // Decoder::do_decode places every result by pos.i, Decoder.h:84-97, so the order is not observable there) and returns the
 // 4 symbol bits plus the drifted position the colour pass used; read_color() returns the 2 colour bits of that cell.
 // CimbDecoder as CimbReader's constructor wants it (cimb_translator/CimbDecoder.h: CimbDecoder(symbol_bits, color_bits, dark, ahashThreshold)):
-// the tile hashes and the colour-correction state live in the device context, so this only names one. 8x8 modes only: 4 symbol bits, 2 colour bits.
+// the tile hashes and the colour-correction state live in the device context, so this only names one; the bit counts must be the context's
+// mode's -- what the reference's callers pass anyway: CimbDecoder(Config::symbol_bits(), Config::color_bits()) (Decoder.h:40-45): 4 + 2, 4 + 3 in mode 8.
 class CimbDecoder
 {
 public:
 	explicit CimbDecoder(Decoder& decoder, unsigned symbol_bits = 4, unsigned color_bits = 2, bool dark = true, unsigned char ahash_threshold = 0xFF)
-	    : _dec(decoder), _ok(symbol_bits == 4 && color_bits == 2 && dark)
+	    : _dec(decoder), _ok(symbol_bits == decoder.symbol_bits() && color_bits == decoder.color_bits() && dark)
 	{
 		(void)ahash_threshold;
 	}
@@ -192,23 +280,32 @@ protected:
 class CimbReader
 {
 public:
-	// CimbReader(const cv::Mat& img, CimbDecoder& decoder, unsigned color_mode, bool needs_sharpen = false, int color_correction = 2)
-	// (cimb_translator/CimbReader.h:16-17). color_mode: only the reference's default for mode B (1) exists here.
+	// CimbReader(const cv::Mat | cv::UMat& img, CimbDecoder& decoder, unsigned color_mode, bool needs_sharpen = false, int color_correction = 2)
+	// (cimb_translator/CimbReader.h:16-17). color_mode: the mode's own palette (Config::color_mode(): 1, or 0 in the legacy modes) is the one built.
 	template <typename MAT>
 	CimbReader(const MAT& img, CimbDecoder& decoder, unsigned color_mode, bool needs_sharpen = false, int color_correction = 2)
 	    : CimbReader(img, decoder.decoder(), needs_sharpen, color_correction)
 	{
-		if (!decoder.good() || color_mode != 1) _good = false;
+		if (!decoder.good() || color_mode != decoder.decoder().color_mode()) _good = false;
 	}
 
 	template <typename MAT>
 	CimbReader(const MAT& img, Decoder& decoder, bool needs_sharpen = false, int color_correction = 2)
 	{
-		unsigned char chunks[CIMBAR_HIP_FRAME_BYTES];
+		detail::with_mat(img, [&](const auto& m) { init(m, decoder, needs_sharpen, color_correction); return 0; });
+	}
+
+protected:
+	template <typename MAT>
+	void init(const MAT& img, Decoder& decoder, bool needs_sharpen, int color_correction)
+	{
+		_good = false;
+		if (!decoder.good()) return;
+		std::vector<unsigned char> chunks(decoder.frame_bytes());   // the context's mode's, not mode B's
 		uint32_t mask = 0;
 		size_t step = (size_t)img.step ? (size_t)img.step : (size_t)img.cols * 3;
-		_good = decoder.good() && cimbar_hip_decode_frame(decoder.context(), reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols,
-		                                                  (unsigned)img.rows, step, needs_sharpen ? 1 : 0, color_correction, chunks, &mask) >= 0;
+		_good = cimbar_hip_decode_frame(decoder.context(), reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
+		                                needs_sharpen ? 1 : 0, color_correction, chunks.data(), &mask) >= 0;
 		if (!_good) return;
 		_cells = decoder.total_cells();
 		_dim_x = (int)decoder.cells_per_col_x(); _dim_y = (int)decoder.cells_per_col_y(); _offset = (int)decoder.cell_offset();
@@ -220,6 +317,7 @@ public:
 		        cimbar_hip_tap(decoder.context(), CIMBAR_HIP_TAP_DRIFT, _drift.data(), _drift.size()) >= 0;
 	}
 
+public:
 	unsigned read(PositionData& pos)
 	{
 		if (done()) return 0;
@@ -282,6 +380,23 @@ public:
 	template <typename MAT, typename CORNERS>
 	image deskew(const MAT& img, const CORNERS& corners)
 	{
+		return detail::with_mat(img, [&](const auto& m) { return deskew_mat(m, corners); });
+	}
+
+	// Scanner::preprocess_image(img, fast = true): 0 / 255 per pixel, what Scanner::scan works on
+	template <typename MAT>
+	image scan_preprocess(const MAT& img)
+	{
+		return detail::with_mat(img, [&](const auto& m) { return scan_preprocess_mat(m); });
+	}
+
+	template <typename MAT>
+	static const unsigned char* dense(const MAT& img, std::vector<unsigned char>& packed) { return dense_rgb(img, packed); }
+
+protected:
+	template <typename MAT, typename CORNERS>
+	image deskew_mat(const MAT& img, const CORNERS& corners)
+	{
 		image out;
 		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return out;
 		float c8[8];
@@ -297,9 +412,8 @@ public:
 		return out;
 	}
 
-	// Scanner::preprocess_image(img, fast = true): 0 / 255 per pixel, what Scanner::scan works on
 	template <typename MAT>
-	image scan_preprocess(const MAT& img)
+	image scan_preprocess_mat(const MAT& img)
 	{
 		image out;
 		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return out;
@@ -312,10 +426,6 @@ public:
 		return out;
 	}
 
-	template <typename MAT>
-	static const unsigned char* dense(const MAT& img, std::vector<unsigned char>& packed) { return dense_rgb(img, packed); }
-
-protected:
 	template <typename MAT>
 	static const unsigned char* dense_rgb(const MAT& img, std::vector<unsigned char>& packed)
 	{
@@ -332,7 +442,8 @@ protected:
 };
 
 // Extractor (extractor/Extractor.h:11-45): Scanner + Corners + Deskewer, all on the device. MAT is anything with data / cols / rows / step
-// that can be re-shaped with create(rows, cols, type) and reports type() -- cv::Mat as is, or cimbar_amd::image.
+// that can be re-shaped with create(rows, cols, type) and reports type() -- cv::Mat as is, cimbar_amd::image, or cv::UMat (through getMat);
+// `out` may be `img` itself, as in cimbar.cpp:146 (`ext.extract(img, img)`): the capture has been consumed before `out` is re-shaped.
 class Extractor
 {
 public:
@@ -346,20 +457,29 @@ public:
 	template <typename MAT>
 	int extract(const MAT& img, MAT& out)
 	{
-		if (!_dec.good() || img.cols <= 0 || img.rows <= 0) return FAILURE;
-		std::vector<unsigned char> packed;
-		const unsigned char* src = Deskewer::dense(img, packed);
+		if (!_dec.good()) return FAILURE;
 		const int fw = (int)_dec.image_size_x(), fh = (int)_dec.image_size_y();
-		std::vector<unsigned char> frame((size_t)fw * fh * 3);
-		int status = 0;
-		if (cimbar_hip_extract_batch(_dec.context(), src, (unsigned)img.cols, (unsigned)img.rows, 1, CIMBAR_HIP_MEM_HOST, frame.data(), &status, _corners,
-		                             CIMBAR_HIP_MEM_HOST, nullptr) != 0)
-			return FAILURE;
+		std::vector<unsigned char> frame;
+		int type = 0;
+		const int status = detail::with_mat(img, [&](const auto& m) {
+			if (m.cols <= 0 || m.rows <= 0) return 0;
+			type = m.type();
+			std::vector<unsigned char> packed;
+			const unsigned char* src = Deskewer::dense(m, packed);
+			frame.resize((size_t)fw * fh * 3);
+			int st = 0;
+			if (cimbar_hip_extract_batch(_dec.context(), src, (unsigned)m.cols, (unsigned)m.rows, 1, CIMBAR_HIP_MEM_HOST, frame.data(), &st, _corners,
+			                             CIMBAR_HIP_MEM_HOST, nullptr) != 0)
+				return 0;
+			return st;
+		});
 		if (status <= 0) return FAILURE;
-		out.create(fh, fw, img.type());
-		for (int y = 0; y < fh; ++y)
-			for (size_t k = 0; k < (size_t)fw * 3; ++k)
-				out.data[(size_t)y * out.step + k] = frame[(size_t)y * fw * 3 + k];
+		out.create(fh, fw, type);
+		detail::with_mat_rw(out, [&](auto& m) {
+			for (int y = 0; y < fh; ++y)
+				for (size_t k = 0; k < (size_t)fw * 3; ++k)
+					m.data[(size_t)y * m.step + k] = frame[(size_t)y * fw * 3 + k];
+		});
 		return status;
 	}
 

@@ -275,6 +275,7 @@ public:
 	UMat(const Mat& m) : Mat(m) {}
 	Mat getMat(AccessFlag) const { return *this; }
 };
+inline UMat getUMat(const Mat& m, AccessFlag) { return UMat(m); }   // stands in for Mat::getUMat (cimbar.cpp:132: cv::imread(..).getUMat(ACCESS_RW)); shares the pixels
 
 template <typename T>
 class MatIterator_

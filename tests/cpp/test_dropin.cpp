@@ -3,8 +3,8 @@
 // the way src/exe/cimbar/cimbar.cpp:124-171,279-296 uses the reference's Decoder. Compiled in the build container against the headers
 // under /root/reference (oracle/Makefile `dropin`), run on the GPU box by tests/test_gpu_cpp_adapter.py.
 //
-//   test_dropin frames.bin n file.bin [captures.bin w h m]
-// frames.bin: n mode-B frames of a fountain stream of file.bin (no compression). captures.bin: m camera captures of w x h.
+//   test_dropin frames.bin n file.bin [captures.bin w h m]          (environment: CIMBAR_MODE = 68 | 67 | 66 | 4 | 8, default 68)
+// frames.bin: n frames (of the mode) of a fountain stream of file.bin (no compression). captures.bin: m camera captures of w x h.
 #include "cimb_translator/Config.h"
 #include "fountain/concurrent_fountain_decoder_sink.h"
 #include "fountain/fountain_decoder_sink.h"
@@ -16,8 +16,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
+
+// src/exe/cimbar/cimbar.cpp:164-172 with the reference's `Decoder&` replaced by the adapter's -- the one-line type swap of INTEGRATION.md 2,
+// the lambda body verbatim: a cv::UMat goes straight into decode_fountain
+template <typename SINK>
+std::function<int(cv::UMat, bool, int)> fountain_decode_fun(SINK& sink, cimbar_amd::Decoder& d)
+{
+	return [&sink, &d](cv::UMat m, bool pre, int cc) {
+		return d.decode_fountain(m, sink, pre, cc);
+	};
+}
 
 static std::vector<unsigned char> slurp(const char* path)
 {
@@ -40,11 +51,21 @@ int main(int argc, char** argv)
 	if (argc < 4) { std::printf("usage: test_dropin frames.bin n file.bin [captures.bin w h m]\n"); return 2; }
 	const int n = std::atoi(argv[2]);
 	std::vector<unsigned char> frames = slurp(argv[1]), file = slurp(argv[3]);
-	const size_t FR = 1024ull * 1024 * 3;
+	const int MODE = std::getenv("CIMBAR_MODE") ? std::atoi(std::getenv("CIMBAR_MODE")) : 68;
+	cimbar::Config::update(MODE);
+	const int W = cimbar::Config::image_size_x(), H = cimbar::Config::image_size_y();
+	const size_t FR = (size_t)W * H * 3;
 	CHECK(frames.size() == FR * (size_t)n && !file.empty());
-	cimbar::Config::update(68);
 	const unsigned chunk = cimbar::Config::fountain_chunk_size();
-	CHECK(chunk == 625);
+	const unsigned long long FB = (unsigned long long)chunk * cimbar::Config::fountain_chunks_per_frame();
+	const int NCELLS = cimbar::Config::total_cells();
+	std::printf("mode %d: %dx%d, %u chunks of %u bytes\n", MODE, W, H, cimbar::Config::fountain_chunks_per_frame(), chunk);
+	{
+		cimbar_amd::Decoder probe(true, true, 0, MODE);
+		// cimbard_get_bufsize() = fountain_chunks_per_frame() * fountain_chunk_size() of the active configuration (cimbar_recv_js.cpp:143-146)
+		CHECK(probe.good() && (unsigned long long)cimbar_hip_ctx_bufsize(probe.context()) == FB && probe.fountain_chunk_size() == chunk);
+		CHECK(probe.color_bits() == cimbar::Config::color_bits() && probe.symbol_bits() == cimbar::Config::symbol_bits() && probe.color_mode() == cimbar::Config::color_mode());
+	}
 
 	// 1. ./cimbar's fountain decode loop (cimbar.cpp:167-171 + :124-162 with --no-deskew): the reference's sink, our Decoder
 	{
@@ -53,15 +74,15 @@ int main(int argc, char** argv)
 		std::vector<unsigned char> recovered;
 		auto on_store = [&recovered](const std::string& name, const std::vector<uint8_t>& bytes) { recovered.assign(bytes.begin(), bytes.end()); return name; };
 		fountain_decoder_sink sink(chunk, on_store);
-		cimbar_amd::Decoder dec;
+		cimbar_amd::Decoder dec(true, true, 0, MODE);
 		CHECK(dec.good());
 		unsigned long long bytes = 0;
 		int used = 0;
 		for (int f = 0; f < n && sink.num_done() == 0; ++f, ++used) {
-			cv::Mat img(1024, 1024, CV_8UC3, frames.data() + FR * f);
+			cv::Mat img(H, W, CV_8UC3, frames.data() + FR * f);
 			bytes += dec.decode_fountain(img, sink);
 		}
-		CHECK(bytes == 7500ull * used);
+		CHECK(bytes == FB * used);
 		CHECK(sink.num_done() == 1);
 		CHECK(recovered.size() == file.size() && std::memcmp(recovered.data(), file.data(), file.size()) == 0);
 		CHECK(sink.is_done(FountainMetadata(9, (unsigned)file.size(), 0).id()));
@@ -71,9 +92,9 @@ int main(int argc, char** argv)
 	{
 		std::vector<unsigned char> recovered;
 		concurrent_fountain_decoder_sink sink(chunk, [&recovered](const std::string& name, const std::vector<uint8_t>& bytes) { recovered.assign(bytes.begin(), bytes.end()); return name; });
-		cimbar_amd::Decoder dec;
+		cimbar_amd::Decoder dec(true, true, 0, MODE);
 		for (int f = 0; f < n && sink.num_done() == 0; ++f) {
-			cv::Mat img(1024, 1024, CV_8UC3, frames.data() + FR * f);
+			cv::Mat img(H, W, CV_8UC3, frames.data() + FR * f);
 			dec.decode_fountain(img, sink);
 			sink.process();
 		}
@@ -85,28 +106,50 @@ int main(int argc, char** argv)
 	{
 		int stored = 0;
 		fountain_decoder_sink sink(chunk, [&stored](const std::string& name, const std::vector<uint8_t>&) { ++stored; return name; });
-		cimbar_amd::Decoder dec;
+		cimbar_amd::Decoder dec(true, true, 0, MODE);
 		unsigned long long bytes = dec.decode_fountain_batch(frames.data(), n, sink);     // chunks after completion are ignored by the sink (:146-148)
-		CHECK(bytes == 7500ull * n);
+		CHECK(bytes == FB * n);
 		CHECK(sink.num_done() == 1 && stored == 1);
 	}
 	// 4. CimbReader in the reference's constructor shape (CimbReader.h:16-17)
 	{
-		cimbar_amd::Decoder dec;
+		cimbar_amd::Decoder dec(true, true, 0, MODE);
 		cimbar_amd::CimbDecoder cd(dec, cimbar::Config::symbol_bits(), cimbar::Config::color_bits());
-		cv::Mat img(1024, 1024, CV_8UC3, frames.data());
+		CHECK(cd.good());
+		cv::Mat img(H, W, CV_8UC3, frames.data());
 		cimbar_amd::CimbReader reader(img, cd, cimbar::Config::color_mode());
-		CHECK(reader.num_reads() == 12400);
+		CHECK((int)reader.num_reads() == NCELLS);
 		unsigned count = 0;
-		while (!reader.done()) { cimbar_amd::PositionData pos; unsigned bits = reader.read(pos); CHECK(bits < 16 && reader.read_color(pos) < 4); ++count; }
-		CHECK(count == 12400);
+		while (!reader.done()) { cimbar_amd::PositionData pos; unsigned bits = reader.read(pos); CHECK(bits < 16 && reader.read_color(pos) < (1u << cimbar::Config::color_bits())); ++count; }
+		CHECK((int)count == NCELLS);
+		// ... and from a cv::UMat (CimbReader.h:17)
+		cv::UMat um = cv::getUMat(img, cv::ACCESS_RW);
+		cimbar_amd::CimbReader ureader(um, cd, cimbar::Config::color_mode());
+		CHECK((int)ureader.num_reads() == NCELLS && !ureader.done());
+	}
+	// 4b. cimbar.cpp's decode loop as it is written there (:124-171): cv::UMat all the way, std::function<int(cv::UMat,bool,int)>, the
+	//     reference's sink -- INTEGRATION.md 2's type swap compiles and runs verbatim
+	{
+		std::vector<unsigned char> recovered;
+		fountain_decoder_sink sink(chunk, [&recovered](const std::string& name, const std::vector<uint8_t>& bytes) { recovered.assign(bytes.begin(), bytes.end()); return name; });
+		cimbar_amd::Decoder d(true, true, 0, MODE);
+		std::function<int(cv::UMat, bool, int)> decodefun = fountain_decode_fun(sink, d);
+		int err = 0;
+		for (int f = 0; f < n && sink.num_done() == 0; ++f) {
+			cv::UMat img = cv::getUMat(cv::Mat(H, W, CV_8UC3, frames.data() + FR * f), cv::ACCESS_RW);   // cimbar.cpp:132: cv::imread(inf).getUMat(cv::ACCESS_RW)
+			int bytes = decodefun(img, false, 2);
+			if (!bytes) err |= 4;
+		}
+		CHECK(err == 0 && sink.num_done() == 1);
+		CHECK(recovered.size() == file.size() && std::memcmp(recovered.data(), file.data(), file.size()) == 0);
+		std::printf("cv::UMat loop: done\n");
 	}
 	// 5. Extractor on cv::Mat captures, then the decode (cimbar.cpp:139-158)
 	if (argc >= 8) {
 		std::vector<unsigned char> caps = slurp(argv[4]);
 		const int w = std::atoi(argv[5]), h = std::atoi(argv[6]), m = std::atoi(argv[7]);
 		CHECK(caps.size() == (size_t)w * h * 3 * m);
-		cimbar_amd::Decoder dec;
+		cimbar_amd::Decoder dec(true, true, 0, MODE);
 		cimbar_amd::Extractor ext(dec);
 		fountain_decoder_sink sink(chunk, [](const std::string& name, const std::vector<uint8_t>&) { return name; });
 		int extracted = 0;
@@ -116,9 +159,17 @@ int main(int argc, char** argv)
 			int res = ext.extract(img, out);
 			if (!res) continue;
 			++extracted;
-			CHECK(out.rows == 1024 && out.cols == 1024);
+			CHECK(out.rows == H && out.cols == W);
 			bool pre = res == cimbar_amd::Extractor::NEEDS_SHARPEN;
-			std::printf("capture %d: extract %d, decoded %u bytes\n", k, res, dec.decode_fountain(out, sink, pre));
+			const unsigned got = dec.decode_fountain(out, sink, pre);
+			std::printf("capture %d: extract %d, decoded %u bytes\n", k, res, got);
+			// cimbar.cpp:132-155 as written: a cv::UMat, extracted IN PLACE (`ext.extract(img, img)`), then decoded
+			cv::UMat u = cv::getUMat(img.clone(), cv::ACCESS_RW);
+			int res2 = ext.extract(u, u);
+			CHECK(res2 == res && u.rows == H && u.cols == W);
+			CHECK(std::memcmp(u.getMat(cv::ACCESS_READ).data, out.data, FR) == 0);
+			fountain_decoder_sink sink2(chunk, [](const std::string& name, const std::vector<uint8_t>&) { return name; });
+			CHECK(dec.decode_fountain(u, sink2, pre) == got);
 		}
 		CHECK(extracted >= 1);
 	}

@@ -1,0 +1,160 @@
+"""GPU: the batch-parallel flood's certificate (k_flood_wave: "no tie-break of the reference's heap could have changed this frame's result")
+checked against the exact replay on ~100 000 distorted frames in three geometries, GPU vs GPU, through the library's own verify mode
+(CIMBAR_HIP_FLOOD_VERIFY=1: every certified frame is replayed exactly and compared cell by cell, CIMBAR_HIP_TAP_FLOOD_VERIFY) -- and the
+exact replay's kernel variants (k_flood3 with six- / five-level pops, k_flood2) against each other and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import decoder as D
+from libcimbar_amd import extractbench, framegen, geometry
+from oracle import pyref
+from tests import frames as F
+
+pytestmark = pytest.mark.gpu
+
+
+def decoder_with(env, mode=68, lib_path=None):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return D.HipDecoder(0, mode, lib_path=lib_path)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def distort_group(fr, g, dev):
+    """one random recipe applied to a group of device frames (n, h, w, 3) uint8: rigid shift, wipe, noise, tear, rescale, or a sub-pixel
+    (bilinear) warp -- and mixes of them"""
+    n, h, w, _ = fr.shape
+    out = torch.roll(fr, shifts=(int(g.integers(-4, 5)), int(g.integers(-4, 5))), dims=(1, 2))
+    kind = int(g.integers(0, 8))
+    if kind == 1:                                   # a wiped block
+        y0, x0 = int(g.integers(0, h - 60)), int(g.integers(0, w - 60))
+        out = out.clone()
+        out[:, y0:y0 + int(g.integers(20, 400)), x0:x0 + int(g.integers(20, 400))] = int(g.integers(0, 256))
+    elif kind == 2:                                 # pixel noise
+        noise = torch.randn(out.shape, device=dev, dtype=torch.float16) * float(g.integers(3, 50))
+        out = (out.to(torch.float16) + noise).round().clamp(0, 255).to(torch.uint8)
+    elif kind == 3:                                 # a tear: two different shifts
+        cut = int(g.integers(100, h - 100))
+        out = torch.cat([torch.roll(fr, shifts=(1, 0), dims=(1, 2))[:, :cut], torch.roll(fr, shifts=(0, 1), dims=(1, 2))[:, cut:]], 1)
+    elif kind == 4:                                 # up to the drift limit
+        out = torch.roll(fr, shifts=(int(g.integers(-7, 8)), int(g.integers(-7, 8))), dims=(1, 2))
+    elif kind in (5, 6):                            # rescale about the centre / small rotation, bilinear (what a deskewed capture looks like)
+        s = 1.0 + float(g.uniform(-0.008, 0.008)) if kind == 5 else 1.0
+        a = float(g.uniform(-0.004, 0.004)) if kind == 6 else 0.0
+        theta = torch.tensor([[s * np.cos(a), -s * np.sin(a) * h / w, float(g.uniform(-0.004, 0.004))],
+                              [s * np.sin(a) * w / h, s * np.cos(a), float(g.uniform(-0.004, 0.004))]], dtype=torch.float32, device=dev)
+        grid = torch.nn.functional.affine_grid(theta[None].expand(n, -1, -1), (n, 3, h, w), align_corners=False)
+        src = out.permute(0, 3, 1, 2).to(torch.float32)
+        out = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="border", align_corners=False)
+        out = out.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8)
+    elif kind == 7:                                 # random 9x9 patches
+        out = out.clone()
+        for _ in range(int(g.integers(1, 30))):
+            y, x = int(g.integers(8, h - 20)), int(g.integers(8, w - 20))
+            out[:, y:y + 9, x:x + 9] = torch.randint(0, 256, (9, 9, 3), device=dev, dtype=torch.uint8)
+    return out.contiguous()
+
+
+@pytest.mark.parametrize("mode,batches", [(68, 50), (67, 26), (66, 24)])
+def test_certificate_holds_on_100k_distorted_frames(mode, batches):
+    """~100 k frames over the three geometries (1024 per batch): every frame k_flood_wave certifies equals its own exact replay"""
+    dev = torch.device("cuda", 0)
+    geo = geometry.for_mode(mode)
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_VERIFY": "1"}, mode)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n, group = 1024, 128
+    g = np.random.default_rng(9000 + mode)
+    frames = torch.empty((n, geo.IMG_H, geo.IMG_W, 3), dtype=torch.uint8, device=dev)
+    chunks = torch.zeros((n, geo.FRAME_BYTES), dtype=torch.uint8, device=dev)
+    masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+    certified = exact = bad = 0
+    for b in range(batches):
+        payload = framegen.synth_payload(n, seed=100 * mode + b, device=dev, mode=mode)
+        dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        dist = torch.cat([distort_group(frames[k:k + group], g, dev) for k in range(0, n, group)], 0).contiguous()
+        dec.decode_batch_device(dist.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, st)
+        torch.cuda.synchronize(dev)
+        path = dec.tap(D.TAP_FLOOD_PATH, n)
+        ver = dec.tap(D.TAP_FLOOD_VERIFY, n)
+        assert ((ver != 0xFFFFFFFF) == (path == 2)).all(), "exactly the certified frames are verified"
+        wrong = np.flatnonzero((path == 2) & (ver != 0))
+        assert wrong.size == 0, f"mode {mode} batch {b}: certified frames {wrong[:8]} differ from their exact replay in {ver[wrong[:8]]} cells"
+        certified += int((path == 2).sum())
+        exact += int((path == 1).sum())
+        del dist
+    dec.close()
+    print(f"mode {mode}: {batches * n} frames, {certified} certified and verified, {exact} exact, 0 differed")
+    assert certified >= batches * n // 8, f"too few frames certified to call this a test: {certified}"
+
+
+def camera_like(synth, n, seed):
+    """deskewed captures: clean frames drawn into 1080p canvases (bilinear) and warped back by the oracle's Extractor"""
+    payload, fr = F.clean_frames(synth, n, seed=seed)
+    caps = extractbench.make_captures(torch.from_numpy(fr)).numpy()
+    L = pyref.oracle_lib()
+    out = []
+    for k in range(n):
+        frame = np.zeros((1024, 1024, 3), np.uint8)
+        c8 = np.zeros(8, np.float32)
+        assert L.co_extract(pyref.P(np.ascontiguousarray(caps[k])), 1920, 1080, pyref.P(frame), pyref.P(c8)) > 0
+        out.append(frame)
+    return out
+
+
+def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
+    """k_flood3 (six- and five-level pops), k_flood2 and the one-wavefront k_flood on shifted, noisy, rescaled, pure-noise and camera-like
+    frames, every flagged frame through the exact replay; two of the camera-like frames also against the oracle (the others GPU vs GPU)"""
+    payload, fr = F.clean_frames(synth, 6, seed=606)
+    g = np.random.default_rng(66)
+    frames = [F.shift(fr[0], 2, 1), F.add_noise(F.shift(fr[1], -3, 2), 40, 7), F.rescale(fr[2], 6), g.integers(0, 256, (1024, 1024, 3), dtype=np.uint8),
+              F.add_noise(fr[3], 90, 3), F.rescale(fr[4], 11), F.shift(fr[5], -7, 7)]
+    frames += camera_like(synth, 4, seed=607)
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    outs = {}
+    for name, env in (("flood3-6", {}), ("flood3-5", {"CIMBAR_HIP_FLOOD_LV6": "0"}), ("flood2", {"CIMBAR_HIP_FLOOD3": "0"}), ("flood1", {"CIMBAR_HIP_FLOOD2": "0"})):
+        dec = decoder_with(dict(env, CIMBAR_HIP_FLOOD_WAVE="0"))
+        for pre in (0, 1):
+            dec.reset_ccm()
+            total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
+            outs[(name, pre)] = (chunks.copy(), masks.copy(), dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_FLOOD_PATH, n))
+        dec.close()
+    for pre in (0, 1):
+        ref = outs[("flood1", pre)]
+        assert (ref[4][:7] == 1).all()
+        for name in ("flood3-6", "flood3-5", "flood2"):
+            o = outs[(name, pre)]
+            for k in range(n):
+                assert (o[2][k] == ref[2][k]).all(), f"{name} pre {pre} frame {k}: {(o[2][k] != ref[2][k]).sum()} symbols differ from the one-wavefront replay"
+                if ref[4][k]:
+                    assert (o[3][k] == ref[3][k]).all(), f"{name} pre {pre} frame {k}: drift differs"
+                assert o[1][k] == ref[1][k] and (o[0][k] == ref[0][k]).all()
+    # the camera-like frames against the oracle (sharpened, as the extractor's NEEDS_SHARPEN verdict would have it)
+    from libcimbar_amd import modeb
+    xy = modeb.cell_positions()
+    o = outs[("flood3-6", 1)]
+    for k in (7, 8):
+        pyref.oracle_decode(frames[k], 1, 2, pyref.CoCcm())
+        wsym, wcol, wpos = pyref.oracle_stage()
+        assert (o[2][k] == wsym).all() and (xy + o[3][k].astype(np.int32) == wpos).all(), f"camera-like frame {k} differs from the oracle"
+
+
+@pytest.mark.parametrize("env", [{}, {"CIMBAR_HIP_FLOOD_LV6": "0"}, {"CIMBAR_HIP_FLOOD3": "0"}], ids=["flood3-6", "flood3-5", "flood2"])
+def test_exact_replay_kernels_with_the_heap_spilling(synth, env):
+    from libcimbar_amd import build as hipbuild
+    from tests.test_gpu_flood import check, flood_frames
+    dec = decoder_with(dict(env, CIMBAR_HIP_FLOOD_WAVE="0"), lib_path=hipbuild.OUT_SPILLTEST)
+    frames, names = flood_frames(synth)
+    frames = frames + camera_like(synth, 1, seed=608)
+    check(dec, frames, names + ["camera-like"])
+    dec.close()

@@ -32,7 +32,7 @@ def padded_cases(mode, seed=3):
     return out
 
 
-@pytest.mark.parametrize("mode", [68, 67, 66, 4])
+@pytest.mark.parametrize("mode", [68, 67, 66, 4, 8])
 def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
     w, h = SIZES[mode]
     with pyref.ref_mode(mode):
@@ -50,7 +50,7 @@ def test_oracle_matches_reference_on_padded_and_small_images(ref, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [68, 67, 66, 4])
+@pytest.mark.parametrize("mode", [68, 67, 66, 4, 8])
 def test_gpu_padded_and_small_images_match_oracle(mode):
     import torch
     if not torch.cuda.is_available():
