@@ -144,6 +144,60 @@ def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
             "payload_sha_match": sha_cpu == sha_gpu, "payload_sha256": sha_cpu}
 
 
+def cpu_baseline_config5(sample, budget_s=10.0):
+    """BASELINE configs[4] on the host cores: the reference's Extractor::extract + Decoder::decode_fountain (oracle/_ref; `preprocess` as
+    cimbar.cpp:147-154 guesses it from the extractor's verdict) over a bounded sample of the SAME 1080p captures, one decoder per thread, and
+    its chunks compared with what the GPU delivered for those captures."""
+    from oracle import pyref
+    import ctypes
+    ref = pyref.ref_lib()
+    if ref is None:
+        return {"error": "oracle/_ref not built: no reference Extractor to time"}
+    caps, g_chunks, g_masks = sample["captures"], sample["chunks"], sample["masks"]
+    k, h, w = caps.shape[0], caps.shape[1], caps.shape[2]
+    ncores = usable_cpus()
+    threads = max(1, min(ncores, 64, k))
+
+    def one(cap, chunks):
+        frame = np.zeros((1024, 1024, 3), np.uint8)
+        mask = ctypes.c_uint32(0)
+        res = ref.ref_extract(pyref.P(cap), w, h, pyref.P(frame))
+        if not res:
+            chunks[:] = 0
+            return 0
+        ref.ref_decode_fountain(pyref.P(frame), 1024, 1024, 1 if res == 2 else 0, 2, 0, pyref.P(chunks), ctypes.byref(mask))
+        return mask.value
+
+    ref.ref_reset_ccm()
+    cpu_chunks = np.zeros((k, 7500), np.uint8)
+    cpu_masks = np.zeros(k, np.uint32)
+    t0 = time.perf_counter()
+    for i in range(k):                       # frame order on one thread: the CCM carries over like in the GPU batch
+        cpu_masks[i] = one(caps[i], cpu_chunks[i])
+    per = (time.perf_counter() - t0) / k
+    same = bool((cpu_masks == g_masks.astype(np.uint32)).all()) and bool((cpu_chunks == g_chunks.reshape(k, -1)).all())
+    total = int(max(threads, 0.6 * budget_s / per * threads))
+    done = [0] * threads
+
+    def worker(tid):
+        buf = np.zeros(7500, np.uint8)
+        for i in range(tid, total, threads):
+            one(caps[i % k], buf)
+            done[tid] += 1
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(sum(done) / dt, 2), "unit": "captures/s", "cores": ncores, "threads": threads, "kind": "reference",
+            "sample": f"{sum(done)} extract + decode runs over {k} of the bench's {w}x{h} captures, {threads} threads x 1 Extractor + Decoder each, "
+                      f"{dt:.1f} s wall, single-thread {1.0 / per:.1f} captures/s",
+            "chunks_equal_gpu": same}
+
+
 def stream_ms(dec, inputs, outs, steps, warmup, pipelined, stream, dev, pre=False):
     """ms per step of a continuous stream of batches (rotating through `inputs`), N = 1, no exchange."""
     D = dec.pipeline_depth if pipelined else 1
@@ -371,10 +425,28 @@ def extras(dec, dev, stream, n, outs, steps):
         d67.close()
       except Exception as e:
         out["mode%d" % other] = {"error": repr(e)}
+    # ---- BASELINE configs[3] at N = 1: the 8192-frame fountain stream of a 16 MiB file, slabs of 1024, the reference's sink fed inside the
+    # timed region by a host thread while the next slab decodes (bench.py --config 4 is the same code under torchrun)
+    try:
+        import bench_config4 as config4
+        torch.cuda.empty_cache()
+        c4 = config4.bench(dec, dev, 0, 1, argparse.Namespace(frames=1024, steps=2, warmup=1))
+        out["config4_n1"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "stage_s", "decode_only_frames_per_s", "end_to_end_over_decode_only", "sink",
+                                                "chunks_match_encoded_stream")}
+        out["config4_n1"]["workload"] = c4["config"]["workload"]
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["config4_n1"] = {"error": repr(e)}
     try:
         from libcimbar_amd import extractbench
-        out.update(extractbench.run(dec, dev, stream, synth))
+        sample = {}
+        out.update(extractbench.run(dec, dev, stream, synth, sample=sample))
         torch.cuda.empty_cache()
+        try:
+            out["config5_extract"]["cpu_baseline"] = cpu_baseline_config5(sample)
+        except Exception as e:
+            out["config5_extract"]["cpu_baseline"] = {"error": repr(e)}
+        del sample
         # the same at 1024 captures per batch: the exact flood keeps one (two-wavefront) workgroup per frame busy for ~35 ms whatever the batch,
         # so the per-batch time barely moves and throughput follows the batch size until every CU holds its four frames
         out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=1, key="config5_extract_1024"))
@@ -458,7 +530,21 @@ def main():
         if not args.no_pipeline:
             dec.pipeline_wait(stream.cuda_stream, keep_newest=keep_newest)
 
-    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered, dst=0)
+    # the exchange is the library's own (cimbar_hip_gather_chunks: ncclGather over RCCL / xGMI issued by libcimbar_hip.so); torch.distributed
+    # is the rendezvous (it carries the communicator id) and the closing barrier, nothing on the data path
+    exchange, exchange_name = None, None
+    if world > 1:
+        try:
+            exchange = multigpu.LibraryGather(dec, dev)
+            exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library)"
+        except Exception as e:          # e.g. no librccl next to this torch build: keep the run alive, say what carried the data
+            exchange, exchange_name = None, f"torch.distributed.gather (library exchange unavailable: {e!r})"
+        flags = torch.tensor([1 if exchange is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # every rank takes the same path
+        if int(flags.item()) == 0 and exchange is not None:
+            exchange.close()
+            exchange, exchange_name = None, "torch.distributed.gather (library exchange unavailable on another rank)"
+    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered, dst=0, gather=exchange)
     step, drain = pipe.step, pipe.drain
 
     def barrier():
@@ -509,6 +595,7 @@ def main():
             "config": {"workload": f"batch of {n} synthetic clean mode-B frames per GPU, device-resident, {R} distinct batches decoded in "
                                    "rotation, bit-exact vs encoded payload",
                        "frames_per_gpu_per_step": n, "distinct_input_batches": R,
+                       "exchange": exchange_name,
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
                                       ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -538,6 +625,8 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        if exchange is not None:
+            exchange.close()
         dist.destroy_process_group()
 
 

@@ -3,7 +3,9 @@
  *     cv::imread(path) + cv::cvtColor(BGR2RGB)        /root/reference/src/exe/cimbar/cimbar.cpp:132-133 (loop :124-162)
  * with a pool of PNG-decoding host threads feeding a ring of pinned batches, whose host->device copies run on a copy stream and overlap
  * the decode of the batch before (cimbar_hip_decode_batch_pipelined). Plain C ABI, C++ inside (libcimbar_ingest.so links zlib, pthreads
- * and libcimbar_hip.so). PNG only (8/16-bit gray, RGB, RGBA, palette; non-interlaced) -- what the reference's encoder writes. */
+ * and libcimbar_hip.so). PNG (1..16-bit gray, RGB, RGBA, gray + alpha, palette; Adam7-interlaced or not) and baseline JPEG (sequential Huffman,
+ * 8 bits, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals; libjpeg's arithmetic, so the pixels are what cv::imread returns) -- what the
+ * reference's encoder writes and what its sample set holds (src/lib/encoder/test/DecoderTest.cpp:60,104). */
 #ifndef CIMBAR_INGEST_H
 #define CIMBAR_INGEST_H
 
@@ -17,7 +19,7 @@ extern "C" {
 #endif
 
 enum {
-	CIMBAR_INGEST_EFORMAT = -20,   /* not a PNG this decoder handles (interlaced, unknown colour type, corrupt stream) */
+	CIMBAR_INGEST_EFORMAT = -20,   /* not a PNG / JPEG these decoders handle (unknown colour type, progressive JPEG, corrupt stream) */
 	CIMBAR_INGEST_EIO = -21,       /* a file could not be read */
 	CIMBAR_INGEST_ESIZE = -22      /* an image is not image_size_x x image_size_y of the context's mode (frames must be deskewed already: the --no-deskew path, cimbar.cpp:136) */
 };
@@ -25,6 +27,12 @@ enum {
 /* One PNG in memory -> tightly packed RGB8 (what cv::imread + BGR2RGB hands the decoder: alpha dropped, gray replicated).
  * rgb may be NULL to query the size: *width / *height are always set. Returns 0 or a negative code. */
 int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height);
+
+/* One baseline JPEG in memory -> RGB8, with libjpeg(-turbo)'s default arithmetic (ISLOW inverse DCT, "fancy" chroma upsampling, the 16-bit
+ * YCbCr tables): what cv::imread + BGR2RGB returns. Progressive / arithmetic-coded / 12-bit / CMYK files: CIMBAR_INGEST_EFORMAT. */
+int cimbar_jpeg_decode(const uint8_t* jpg, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height);
+/* either of the two, by the file's first bytes */
+int cimbar_image_decode(const uint8_t* file, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height);
 
 typedef struct cimbar_ingest cimbar_ingest;
 
@@ -43,8 +51,9 @@ int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int
  *   CIMBAR_INGEST_PNG_DEVICE : the host threads only read the files and copy their IDAT payloads into the pinned batch; the compressed bytes
  *       cross PCIe and cimbar_hip_png_decode_batch (include/cimbar_hip.h) inflates and un-filters them on the device, straight into the
  *       frames the decoder reads. Takes what cv::imwrite / any ordinary tool writes (8 bits per sample, gray / RGB / RGBA / palette, not
- *       interlaced); a file outside that, or whose stream the device refuses (invalid deflate data, Adler-32 mismatch), is skipped like an
- *       unreadable one. There is no host fallback inside this mode. batch_frames <= 0: 512 (the inflate pass runs one wavefront per image:
+ *       interlaced). A file outside that -- a JPEG, a 16-bit / sub-byte / Adam7 PNG -- is decoded by the host thread that read it and its frame
+ *       joins the batch on the device (up to 32 such files per batch; cimbar_ingest_host_decoded counts them); a PNG whose stream the device
+ *       refuses (invalid deflate data, Adler-32 mismatch) is skipped like an unreadable one. batch_frames <= 0: 512 (the inflate pass runs one wavefront per image:
  *       large batches are what fills the GPU); zbytes_per_frame: pinned + device room for a frame's compressed stream (0: a quarter of the
  *       decoded frame; a batch whose streams together exceed batch_frames * zbytes_per_frame loses the files that no longer fit).
  *       cimbar_ingest_run_raw is not available on such an ingest. */
@@ -53,6 +62,8 @@ int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, 
 /* device PNG mode, last cimbar_ingest_run_files: [0] files seen, [1] refused by the host's chunk walk (or unreadable / wrong size / no room),
  * [2] refused by the device, [3] bytes copied to the device */
 int cimbar_ingest_png_stats(const cimbar_ingest* ing, int64_t out4[4]);
+/* device PNG mode, last cimbar_ingest_run_files: files decoded on the host instead (JPEG, PNGs the kernels do not take) */
+int64_t cimbar_ingest_host_decoded(const cimbar_ingest* ing);
 void cimbar_ingest_destroy(cimbar_ingest* ing);
 const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
 

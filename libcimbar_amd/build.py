@@ -56,7 +56,7 @@ INGEST_HEADER = os.path.join(os.path.dirname(HERE), "include", "cimbar_ingest.h"
 
 def build_ingest(force=False, verbose=False):
     """libcimbar_ingest.so: the host-side PNG pool + pinned ring in front of the device path (plain C++, g++; HIP runtime API only)."""
-    deps = [INGEST_SRC, INGEST_HEADER, HEADER]
+    deps = [INGEST_SRC, os.path.join(HERE, "csrc", "jpeg.inc"), INGEST_HEADER, HEADER]
     if not force and os.path.exists(INGEST_OUT) and os.path.getmtime(INGEST_OUT) >= max(os.path.getmtime(p) for p in deps) \
             and os.path.getmtime(INGEST_OUT) >= os.path.getmtime(OUT):
         return INGEST_OUT

@@ -42,7 +42,8 @@ int paeth(int a, int b, int c)
 }
 
 // PNG (ISO/IEC 15948): signature, IHDR, [PLTE], IDAT..., IEND; zlib stream of filtered scanlines. Output: RGB8, alpha dropped, gray
-// replicated, 16-bit samples reduced to their high byte -- what cv::imread(IMREAD_COLOR) followed by BGR2RGB gives the reference.
+// replicated, 16-bit samples reduced to their high byte, Adam7 passes put back together -- what cv::imread(IMREAD_COLOR) followed by BGR2RGB
+// gives the reference.
 int png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t cap, unsigned* pw, unsigned* ph, std::vector<uint8_t>& idat, std::vector<uint8_t>& raw)
 {
 	static const uint8_t SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
@@ -75,7 +76,7 @@ int png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t cap, unsigne
 	if (!have_ihdr || w == 0 || h == 0 || w > 32768 || h > 32768) return CIMBAR_INGEST_EFORMAT;
 	if (pw) *pw = w;
 	if (ph) *ph = h;
-	if (interlace != 0) return CIMBAR_INGEST_EFORMAT;
+	if (interlace > 1) return CIMBAR_INGEST_EFORMAT;
 	unsigned channels;
 	switch (ctype) {
 		case 0: channels = 1; break;
@@ -89,46 +90,67 @@ int png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t cap, unsigne
 	if (ctype == 3 && depth == 16) return CIMBAR_INGEST_EFORMAT;
 	if (!rgb) return 0;
 	if (cap < (size_t)w * h * 3) return CIMBAR_HIP_EINVAL;
-	const size_t bits_pp = (size_t)channels * depth, row_bytes = (w * bits_pp + 7) / 8, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
-	raw.resize((row_bytes + 1) * (size_t)h);
+	const size_t bits_pp = (size_t)channels * depth, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+	// the reduced images the stream holds one after the other: the whole image, or Adam7's seven passes (ISO/IEC 15948 8.2):
+	// pass p covers pixels (x0 + i * dx, y0 + j * dy)
+	struct Pass { unsigned x0, y0, dx, dy; };
+	static const Pass ADAM7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+	static const Pass WHOLE = {0, 0, 1, 1};
+	const int npass = interlace ? 7 : 1;
+	size_t total = 0;
+	for (int p = 0; p < npass; ++p) {
+		const Pass& ps = interlace ? ADAM7[p] : WHOLE;
+		const size_t pw_ = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph_ = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+		if (pw_ && ph_) total += ((pw_ * bits_pp + 7) / 8 + 1) * ph_;
+	}
+	raw.resize(total);
 	uLongf out_len = (uLongf)raw.size();
 	if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return CIMBAR_INGEST_EFORMAT;
-	// un-filter in place (filter type byte in front of every scanline)
-	for (unsigned y = 0; y < h; ++y) {
-		uint8_t* cur = raw.data() + (row_bytes + 1) * (size_t)y + 1;
-		const uint8_t* up = y ? cur - (row_bytes + 1) : nullptr;
-		switch (cur[-1]) {
-			case 0: break;
-			case 1: for (size_t i = bpp; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
-			case 2: if (up) for (size_t i = 0; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
-			case 3:
-				for (size_t i = 0; i < row_bytes; ++i) {
-					const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
-					cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
-				}
-				break;
-			case 4:
-				for (size_t i = 0; i < row_bytes; ++i) {
-					const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-					cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
-				}
-				break;
-			default: return CIMBAR_INGEST_EFORMAT;
-		}
-		uint8_t* dst = rgb + (size_t)y * w * 3;
-		if (depth == 8 && ctype == 2) { std::memcpy(dst, cur, (size_t)w * 3); continue; }
-		for (unsigned x = 0; x < w; ++x) {
-			unsigned s[4] = {0, 0, 0, 0};
-			if (depth == 8) for (unsigned c = 0; c < channels; ++c) s[c] = cur[(size_t)x * channels + c];
-			else if (depth == 16) for (unsigned c = 0; c < channels; ++c) s[c] = cur[((size_t)x * channels + c) * 2];
-			else {
-				const unsigned per = 8 / depth, v = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1u << depth) - 1u);
-				s[0] = ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+	size_t base = 0;
+	for (int p = 0; p < npass; ++p) {
+		const Pass& ps = interlace ? ADAM7[p] : WHOLE;
+		const size_t pw_ = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph_ = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+		if (!pw_ || !ph_) continue;
+		const size_t row_bytes = (pw_ * bits_pp + 7) / 8;
+		// un-filter in place (filter type byte in front of every scanline)
+		for (size_t y = 0; y < ph_; ++y) {
+			uint8_t* cur = raw.data() + base + (row_bytes + 1) * y + 1;
+			const uint8_t* up = y ? cur - (row_bytes + 1) : nullptr;
+			switch (cur[-1]) {
+				case 0: break;
+				case 1: for (size_t i = bpp; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+				case 2: if (up) for (size_t i = 0; i < row_bytes; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+				case 3:
+					for (size_t i = 0; i < row_bytes; ++i) {
+						const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+						cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+					}
+					break;
+				case 4:
+					for (size_t i = 0; i < row_bytes; ++i) {
+						const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+						cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+					}
+					break;
+				default: return CIMBAR_INGEST_EFORMAT;
 			}
-			if (ctype == 3) { const unsigned i = s[0] < npal ? s[0] : 0; dst[3 * x] = pal[i][0]; dst[3 * x + 1] = pal[i][1]; dst[3 * x + 2] = pal[i][2]; }
-			else if (ctype == 0 || ctype == 4) { dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = (uint8_t)s[0]; }
-			else { dst[3 * x] = (uint8_t)s[0]; dst[3 * x + 1] = (uint8_t)s[1]; dst[3 * x + 2] = (uint8_t)s[2]; }
+			const size_t oy = ps.y0 + y * ps.dy;
+			if (!interlace && depth == 8 && ctype == 2) { std::memcpy(rgb + oy * w * 3, cur, (size_t)w * 3); continue; }
+			for (size_t x = 0; x < pw_; ++x) {
+				unsigned smp[4] = {0, 0, 0, 0};
+				if (depth == 8) for (unsigned c = 0; c < channels; ++c) smp[c] = cur[x * channels + c];
+				else if (depth == 16) for (unsigned c = 0; c < channels; ++c) smp[c] = cur[(x * channels + c) * 2];
+				else {
+					const unsigned per = 8 / depth, v = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1u << depth) - 1u);
+					smp[0] = ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+				}
+				uint8_t* dst = rgb + (oy * w + ps.x0 + x * ps.dx) * 3;
+				if (ctype == 3) { const unsigned i = smp[0] < npal ? smp[0] : 0; dst[0] = pal[i][0]; dst[1] = pal[i][1]; dst[2] = pal[i][2]; }
+				else if (ctype == 0 || ctype == 4) { dst[0] = dst[1] = dst[2] = (uint8_t)smp[0]; }
+				else { dst[0] = (uint8_t)smp[0]; dst[1] = (uint8_t)smp[1]; dst[2] = (uint8_t)smp[2]; }
+			}
 		}
+		base += (row_bytes + 1) * ph_;
 	}
 	return 0;
 }
@@ -162,6 +184,15 @@ int png_walk(const uint8_t* png, size_t len, PngInfo& info)
 	if (!(info.ctype == 0 || info.ctype == 2 || info.ctype == 3 || info.ctype == 6) || info.zlen < 6 || info.zlen >= (1u << 28)) return CIMBAR_INGEST_EFORMAT;   // the device kernels' bit positions are 32-bit: streams below 256 MiB (cimbar_hip.h)
 	if (info.ctype == 3 && !info.plte) return CIMBAR_INGEST_EFORMAT;
 	return 0;
+}
+
+#include "jpeg.inc"
+
+// what cv::imread(path) + cvtColor(BGR2RGB) makes of a file (cimbar.cpp:132-133), by its magic bytes: PNG or (baseline) JPEG
+int image_decode(const uint8_t* file, size_t len, uint8_t* rgb, size_t cap, unsigned* pw, unsigned* ph, std::vector<uint8_t>& idat, std::vector<uint8_t>& raw)
+{
+	if (len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return jpeg::decode(file, len, rgb, cap, pw, ph);
+	return png_decode(file, len, rgb, cap, pw, ph, idat, raw);
 }
 
 bool read_file(const char* path, std::vector<uint8_t>& out)
@@ -203,14 +234,19 @@ struct cimbar_ingest {
 		int32_t* h_status = nullptr; int32_t* d_status = nullptr;
 		hipStream_t png_stream = nullptr;
 		hipEvent_t copied = nullptr;
+		// ... and the files the device kernels do not take (JPEG; 16-bit, sub-byte, Adam7 PNGs): decoded by the host thread into one of FB
+		// pinned frames and copied into the batch behind the PNG kernels
+		uint8_t* h_fb = nullptr;
+		std::vector<int> fb_index;                                              // per frame of the batch: its pinned fallback frame, or -1
 	};
+	static constexpr int FB = 32;     // host-decoded frames a device-mode batch can take
 	int png_mode = CIMBAR_INGEST_PNG_HOST;
 	size_t zcap = 0;                  // bytes of h_z / d_z per slot
 	size_t scratch_stride = 0;
 	std::vector<Slot> slots;
 	hipStream_t copy_stream = nullptr, out_stream = nullptr;
 	double t_wall = 0, t_host = 0, t_wait = 0;
-	int64_t png_files = 0, png_refused_host = 0, png_refused_device = 0, png_bytes = 0;   // device PNG mode, last run
+	int64_t png_files = 0, png_refused_host = 0, png_refused_device = 0, png_bytes = 0, host_decoded = 0;   // device PNG mode, last run
 };
 
 namespace {
@@ -228,6 +264,8 @@ namespace {
 // file's zlib stream + descriptor, the space taken from the batch's cursor) and says whether it is a usable frame
 // direct != nullptr: the frames already sit in page-locked host memory (hipHostMalloc / hipHostRegister) -- no staging threads, the H2D
 // copies read the caller's buffer
+constexpr size_t ZMASK = ((size_t)1 << 48) - 1, FB_ONE = (size_t)1 << 48;
+
 template <typename FILL>
 int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_sink_fn sink, void* user, FILL fill, const uint8_t* direct = nullptr)
 {
@@ -235,9 +273,10 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 	ICHK(hipSetDevice(ing->device));
 	const int B = ing->B, R = ing->R, nbatch = (n + B - 1) / B;
 	const bool dev_png = ing->png_mode == CIMBAR_INGEST_PNG_DEVICE;
+	// per batch: bytes of compressed streams handed out (low 48 bits) and host-decoded fallback frames handed out (the bits above)
 	std::unique_ptr<std::atomic<size_t>[]> zcur(new std::atomic<size_t>[(size_t)nbatch]);
 	for (int k = 0; k < nbatch; ++k) zcur[(size_t)k].store(0);
-	ing->png_files = ing->png_refused_host = ing->png_refused_device = ing->png_bytes = 0;
+	ing->png_files = ing->png_refused_host = ing->png_refused_device = ing->png_bytes = ing->host_decoded = 0;
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<int> filled((size_t)nbatch, 0);      // frames of batch k staged so far
@@ -293,6 +332,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			if (dev_png) {
 				ing->png_files += 1;
 				if (!sl.valid[(size_t)j]) ing->png_refused_host += 1;
+				else if (sl.fb_index[(size_t)j] >= 0) ing->host_decoded += 1;            // (its descriptor was empty: the device's verdict on it means nothing)
 				else if (sl.h_status[j] != 0) { ing->png_refused_device += 1; sl.valid[(size_t)j] = 0; }
 			}
 			if (!sl.valid[(size_t)j]) { sl.h_masks[j] = 0; std::memset(sl.h_chunks + (size_t)j * ing->frame_bytes, 0, ing->frame_bytes); }
@@ -320,7 +360,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 		if (dev_png) {
 			// the compressed bytes and the descriptors go over on the copy stream; the slot's own stream inflates and un-filters them into
 			// d_in (so that consecutive batches' inflate passes overlap) and is what the decoder then waits for
-			const size_t zbytes = (zcur[(size_t)k].load() + 15) & ~(size_t)15;
+			const size_t zbytes = ((zcur[(size_t)k].load() & ZMASK) + 15) & ~(size_t)15;
 			ing->png_bytes += (int64_t)zbytes;
 			hipError_t e = zbytes ? hipMemcpyAsync(sl.d_z, sl.h_z, zbytes < ing->zcap ? zbytes : ing->zcap, hipMemcpyHostToDevice, ing->copy_stream) : hipSuccess;
 			if (e == hipSuccess) e = hipMemcpyAsync(sl.d_desc, sl.h_desc, sizeof(cimbar_hip_png_desc) * (size_t)m, hipMemcpyHostToDevice, ing->copy_stream);
@@ -331,6 +371,10 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 			r = cimbar_hip_png_decode_batch_v(ing->device, sl.d_z, ing->zcap, sl.d_desc, m, sl.d_scratch, ing->scratch_stride, sl.d_in, ing->frame, sl.d_status,
 			                                  (long)B * R >= 8192 ? 4 : 0, sl.png_stream);
 			if (r != 0) { ing->err = "cimbar_hip_png_decode_batch failed to launch"; rc = r; break; }
+			for (int j = 0; j < m && e == hipSuccess; ++j)                               // host-decoded frames join the batch behind the PNG kernels
+				if (sl.valid[(size_t)j] && sl.fb_index[(size_t)j] >= 0)
+					e = hipMemcpyAsync(sl.d_in + (size_t)j * ing->frame, sl.h_fb + (size_t)sl.fb_index[(size_t)j] * ing->frame, ing->frame, hipMemcpyHostToDevice, sl.png_stream);
+			if (e != hipSuccess) { ing->err = std::string("copy of a host-decoded frame: ") + hipGetErrorString(e); rc = CIMBAR_HIP_EHIP; break; }
 			r = cimbar_hip_decode_batch_pipelined(ing->ctx, sl.d_in, m, pre, cc, sl.d_chunks, sl.d_masks, sl.png_stream);
 		} else {
 			hipError_t e = hipMemcpyAsync(sl.d_in, direct ? direct + (size_t)k * B * ing->frame : sl.h_in, (size_t)m * ing->frame, hipMemcpyHostToDevice, ing->copy_stream);
@@ -385,6 +429,21 @@ int cimbar_png_decode(const uint8_t* png, size_t len, uint8_t* rgb, size_t rgb_c
 	std::vector<uint8_t> idat, raw;
 	return png_decode(png, len, rgb, rgb_capacity, width, height, idat, raw);
 }
+
+int cimbar_jpeg_decode(const uint8_t* jpg, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height)
+{
+	if (!jpg) return CIMBAR_HIP_EINVAL;
+	return jpeg::decode(jpg, len, rgb, rgb_capacity, width, height);
+}
+
+int cimbar_image_decode(const uint8_t* file, size_t len, uint8_t* rgb, size_t rgb_capacity, unsigned* width, unsigned* height)
+{
+	if (!file) return CIMBAR_HIP_EINVAL;
+	std::vector<uint8_t> idat, raw;
+	return image_decode(file, len, rgb, rgb_capacity, width, height, idat, raw);
+}
+
+int64_t cimbar_ingest_host_decoded(const cimbar_ingest* ing) { return ing ? ing->host_decoded : CIMBAR_HIP_EINVAL; }
 
 int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out)
 {
@@ -450,6 +509,8 @@ int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, 
 			if (hipMalloc((void**)&s.d_status, nb * sizeof(int32_t)) != hipSuccess) return fail("device status");
 			if (hipStreamCreateWithFlags(&s.png_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
 			if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) return fail("event");
+			if (hipHostMalloc((void**)&s.h_fb, (size_t)cimbar_ingest::FB * ing->frame, hipHostMallocDefault) != hipSuccess) return fail("pinned fallback frames");
+			s.fb_index.assign(nb, -1);
 			std::memset(s.h_desc, 0, nb * sizeof(cimbar_hip_png_desc));
 		} else if (hipHostMalloc((void**)&s.h_in, nb * ing->frame, hipHostMallocDefault) != hipSuccess) return fail("pinned input");
 		if (hipMalloc((void**)&s.d_in, nb * ing->frame) != hipSuccess) return fail("device input");
@@ -477,6 +538,7 @@ void cimbar_ingest_destroy(cimbar_ingest* ing)
 		if (s.d_masks) (void)hipFree(s.d_masks);
 		if (s.done) (void)hipEventDestroy(s.done);
 		if (s.h_z) (void)hipHostFree(s.h_z);
+		if (s.h_fb) (void)hipHostFree(s.h_fb);
 		if (s.d_z) (void)hipFree(s.d_z);
 		if (s.h_desc) (void)hipHostFree(s.h_desc);
 		if (s.d_desc) (void)hipFree(s.d_desc);
@@ -502,13 +564,25 @@ int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, in
 		auto fillz = [&](int i, cimbar_ingest::Slot& sl, int j, std::atomic<size_t>& cursor) -> bool {
 			thread_local std::vector<uint8_t> file;
 			thread_local PngInfo info;
+			thread_local std::vector<uint8_t> idat, raw;
 			cimbar_hip_png_desc& d = sl.h_desc[j];
 			std::memset(&d, 0, sizeof d);                   // (zlen 0: the device refuses the slot)
+			sl.fb_index[(size_t)j] = -1;
 			if (!read_file(paths[i], file)) return false;
-			if (png_walk(file.data(), file.size(), info) != 0) return false;
+			if (png_walk(file.data(), file.size(), info) != 0) {
+				// not a PNG the kernels take -- a JPEG, a 16-bit / sub-byte / interlaced PNG: this thread decodes it (what cv::imread would have
+				// made of it) into one of the batch's pinned fallback frames, which joins the batch on the device
+				unsigned w = 0, h = 0;
+				if (image_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0 || w != ing->fw || h != ing->fh) return false;
+				const size_t idx = cursor.fetch_add(FB_ONE) >> 48;
+				if (idx >= (size_t)cimbar_ingest::FB) return false;      // more such files in one batch than it has room for: skipped
+				if (image_decode(file.data(), file.size(), sl.h_fb + idx * ing->frame, ing->frame, &w, &h, idat, raw) != 0) return false;
+				sl.fb_index[(size_t)j] = (int)idx;
+				return true;
+			}
 			if (info.w != ing->fw || info.h != ing->fh) return false;
 			const size_t zal = (info.zlen + 15) & ~(size_t)15, need = zal + (info.ctype == 3 ? 768 : 0);
-			const size_t off = cursor.fetch_add(need);
+			const size_t off = cursor.fetch_add(need) & ZMASK;
 			if (off + need > ing->zcap) return false;       // the batch's compressed bytes do not fit: see cimbar_ingest_create_ex
 			uint8_t* dst = sl.h_z + off;
 			for (const auto& seg : info.idat) { std::memcpy(dst, seg.first, seg.second); dst += seg.second; }
@@ -529,9 +603,9 @@ int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, in
 		uint8_t* dst = sl.h_in + (size_t)j * ing->frame;
 		if (!read_file(paths[i], file)) return false;
 		unsigned w = 0, h = 0;
-		if (png_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0) return false;
+		if (image_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0) return false;
 		if (w != ing->fw || h != ing->fh) return false;   // (larger, padded frames: not supported on this path)
-		return png_decode(file.data(), file.size(), dst, ing->frame, &w, &h, idat, raw) == 0;
+		return image_decode(file.data(), file.size(), dst, ing->frame, &w, &h, idat, raw) == 0;
 	};
 	return run_pipeline(ing, nfiles, should_preprocess, color_correction, sink, user, fill);
 }

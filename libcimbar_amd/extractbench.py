@@ -47,7 +47,8 @@ def make_captures(frames, width=1920, height=1080, background=24):
     return out
 
 
-def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract"):
+def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=None):
+    """sample: an empty dict; receives the first 32 captures (host) and what the GPU delivered for them, for the caller's CPU baseline"""
     payload = framegen.synth_payload(n, seed=777, device=dev)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
     dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), stream.cuda_stream)
@@ -80,6 +81,9 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract"):
         best_ext = de if best_ext is None or de < best_ext else best_ext
     st = status.cpu().numpy()
     m = masks.cpu().numpy()
+    if sample is not None:
+        k = min(n, 32)
+        sample.update(captures=caps[:k].cpu().numpy(), chunks=chunks[:k].cpu().numpy(), masks=m[:k].copy(), status=st[:k].copy())
     full = (m == 0xFFF)
     payload_ok = bool((chunks[torch.from_numpy(full).to(dev)] == payload[torch.from_numpy(full).to(dev)]).all().item())
     path = dec.tap(7, n)

@@ -10,7 +10,8 @@ from . import decoder
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_ingest.so")
 EXPORTS = ("cimbar_png_decode", "cimbar_ingest_create", "cimbar_ingest_destroy", "cimbar_ingest_last_error", "cimbar_ingest_run_files",
-           "cimbar_ingest_run_raw", "cimbar_ingest_timings", "cimbar_ingest_create_ex", "cimbar_ingest_png_stats")
+           "cimbar_ingest_run_raw", "cimbar_ingest_timings", "cimbar_ingest_create_ex", "cimbar_ingest_png_stats", "cimbar_jpeg_decode",
+           "cimbar_image_decode", "cimbar_ingest_host_decoded")
 PNG_HOST, PNG_DEVICE = 0, 1
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int)
 
@@ -27,6 +28,11 @@ def load_library():
         vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         L.cimbar_png_decode.argtypes = [vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
         L.cimbar_png_decode.restype = i32
+        for fn in (L.cimbar_jpeg_decode, L.cimbar_image_decode):
+            fn.argtypes = [vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+            fn.restype = i32
+        L.cimbar_ingest_host_decoded.argtypes = [vp]
+        L.cimbar_ingest_host_decoded.restype = ctypes.c_int64
         L.cimbar_ingest_create.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
         L.cimbar_ingest_create.restype = i32
         L.cimbar_ingest_create_ex.argtypes = [vp, i32, i32, i32, i32, sz, ctypes.POINTER(vp)]
@@ -45,6 +51,31 @@ def load_library():
         L.cimbar_ingest_timings.restype = i32
         _lib = L
     return _lib
+
+
+def _decode_with(fn_name, data):
+    L = load_library()
+    fn = getattr(L, fn_name)
+    buf = np.frombuffer(data, np.uint8)
+    w, h = ctypes.c_uint(0), ctypes.c_uint(0)
+    rc = fn(buf.ctypes.data, buf.size, None, 0, ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        raise decoder.CimbarHipError(f"{fn_name}: {rc}")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    rc = fn(buf.ctypes.data, buf.size, out.ctypes.data, out.size, ctypes.byref(w), ctypes.byref(h))
+    if rc != 0:
+        raise decoder.CimbarHipError(f"{fn_name}: {rc}")
+    return out
+
+
+def jpeg_decode(data):
+    """baseline JPEG bytes -> (h, w, 3) uint8 RGB with libjpeg's arithmetic (what cv::imread + BGR2RGB returns)"""
+    return _decode_with("cimbar_jpeg_decode", data)
+
+
+def image_decode(data):
+    """PNG or JPEG, by the magic bytes"""
+    return _decode_with("cimbar_image_decode", data)
 
 
 def png_decode(data):
@@ -122,6 +153,10 @@ class Ingest:
         out = (ctypes.c_int64 * 4)()
         self._lib.cimbar_ingest_png_stats(self._h, out)
         return {"files": out[0], "refused_by_host_walk": out[1], "refused_by_device": out[2], "bytes_to_device": out[3]}
+
+    def host_decoded(self):
+        """device PNG mode, last run_files: files the host threads decoded instead (JPEG, PNGs the kernels do not take)"""
+        return int(self._lib.cimbar_ingest_host_decoded(self._h))
 
     def timings(self):
         out = (ctypes.c_double * 3)()

@@ -45,6 +45,58 @@ def gather_chunks(chunks, masks, dst=0, group=None, out=None, async_op=False):
     return (all_c, all_m, works) if async_op else (all_c, all_m)
 
 
+class _EventWork:
+    """what StepPipeline needs of an exchange in flight: wait() orders the current stream behind it"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class LibraryGather:
+    """The product's own exchange, cimbar_hip_gather_chunks (RCCL ncclGather issued by libcimbar_hip.so, csrc/comm.hip.inc), as a drop-in
+    for gather_chunks(..., async_op=True): the gather runs on a side stream that waits for what the current stream has been told to wait
+    for, so it overlaps the decode steps issued afterwards. torch.distributed only carries the 128-byte communicator id to the ranks
+    (rendezvous); no torch collective touches the data path."""
+
+    def __init__(self, dec, dev, group=None):
+        self.dec, self.dev, self.group = dec, dev, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        from . import decoder as _d
+        box = [_d.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.comm = dec.comm_init_rank(box[0], self.world, self.rank)
+        self.stream = torch.cuda.Stream(dev)
+
+    def __call__(self, chunks, masks, dst=0, group=None, out=None, async_op=True):
+        if self.rank == dst and out is None:
+            n_r = chunks.shape[0]
+            out = (torch.empty((self.world * n_r, chunks.shape[1]), dtype=chunks.dtype, device=chunks.device),
+                   torch.empty((self.world * n_r,), dtype=masks.dtype, device=masks.device))
+        all_c, all_m = out if self.rank == dst else (None, None)
+        before = torch.cuda.Event()
+        before.record(torch.cuda.current_stream(self.dev))
+        self.stream.wait_event(before)
+        self.dec.gather_chunks(self.comm, dst, chunks.data_ptr(), masks.data_ptr(), chunks.shape[0],
+                               all_c.data_ptr() if all_c is not None else 0, all_m.data_ptr() if all_m is not None else 0, self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        work = _EventWork(done)
+        if not async_op:
+            work.wait()
+            return all_c, all_m
+        return all_c, all_m, [work]
+
+    def close(self):
+        from . import decoder as _d
+        if self.comm is not None:
+            torch.cuda.synchronize(self.dev)
+            _d.comm_destroy(self.comm)
+            self.comm = None
+
+
 class StepPipeline:
     """Host-side bookkeeping for a continuous stream of decode steps on one rank (what bench.py's timed loop is):
 
@@ -56,8 +108,9 @@ class StepPipeline:
     issue(buf, step) enqueues one decode into outs[buf]; ready(keep_newest) makes the current stream wait for every issued step
     except the `keep_newest` most recent ones. Both are callables so that the CPU test can drive the same logic with gloo."""
 
-    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None):
+    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None, gather=None):
         self.outs, self.depth, self.issue, self.ready = outs, max(1, int(depth)), issue, ready
+        self.gather_fn = gather if gather is not None else gather_chunks     # e.g. a LibraryGather: the library's own RCCL exchange
         self.nbuf = len(outs)
         assert self.nbuf >= self.depth, "one output buffer set per step in flight"
         self.gathered = gathered if gathered is not None else [None] * self.nbuf
@@ -74,7 +127,7 @@ class StepPipeline:
             return
         self.fresh[b] = False
         chunks, masks = self.outs[b]
-        all_c, all_m, self.pending[b] = gather_chunks(chunks, masks, dst=self.dst, group=self.group, out=self.gathered[b], async_op=True)
+        all_c, all_m, self.pending[b] = self.gather_fn(chunks, masks, dst=self.dst, group=self.group, out=self.gathered[b], async_op=True)
         self.last = (all_c, all_m)
         self.gathers += 1
 

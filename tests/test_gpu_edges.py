@@ -98,10 +98,11 @@ def test_bad_arguments_are_refused(hip_decoder):
     assert good == 625 * bin(m).count("1")   # (a black frame is all-zero RS codewords: the reference "decodes" some of it too)
 
 
-def test_unsupported_modes_and_devices_fail_loudly():
-    for mode in (5, 12345):   # (every mode of Config::temp_conf is built: 68, 67, 66, 4, 8 -- test_gpu_modes.py)
-        with pytest.raises(D.CimbarHipError):
-            D.HipDecoder(device=0, mode=mode)
+def test_unknown_modes_are_mode_b_and_bad_devices_fail_loudly():
+    for mode in (5, 12345):   # Config::temp_conf's `case 68: default:` (Config.h:41-43): any value that is no listed mode is mode B, upstream and here
+        d = D.HipDecoder(device=0, mode=mode)
+        assert d.geo.MODE == 68 and d.bufsize() == 7500
+        d.close()
     with pytest.raises(D.CimbarHipError):
         D.HipDecoder(device=4096)
     d = D.HipDecoder(device=0, mode=0)   # 0 = the reference's default config == mode B

@@ -99,7 +99,7 @@ def test_certificate_holds_on_100k_distorted_frames(mode, batches):
 
 def camera_like(synth, n, seed):
     """deskewed captures: clean frames drawn into 1080p canvases (bilinear) and warped back by the oracle's Extractor"""
-    payload, fr = F.clean_frames(synth, n, seed=seed)
+    payload, fr = F.clean_frames(synth, max(n, 4), seed=seed)     # (make_captures deals its quads round robin: at least one frame per quad)
     caps = extractbench.make_captures(torch.from_numpy(fr)).numpy()
     L = pyref.oracle_lib()
     out = []

@@ -177,8 +177,9 @@ def test_other_sizes_and_both_modes_coexist(dec67, synth67, hip_decoder, synth, 
         _, cb, mb = hip_decoder.decode_frame(fb[k])
         _, cm, mm = dec67.decode_frame(fm[k])
         assert mb == 0xFFF and mm == GEO.FULL_MASK and (cb.reshape(-1) == pb[k]).all() and (cm.reshape(-1) == pm[k]).all()
-    with pytest.raises(D.CimbarHipError):
-        D.HipDecoder(0, 5)           # not a mode of Config::temp_conf
+    other = D.HipDecoder(0, 5)       # not a mode of Config::temp_conf: its `default:` branch, i.e. mode B (Config.h:41-43)
+    assert other.geo.MODE == 68 and other.bufsize() == 7500 and dec67.bufsize() == GEO.FRAME_BYTES
+    other.close()
 
 
 def test_camera_captures_scan_extract_decode(dec67, synth67, MODE, GEO):

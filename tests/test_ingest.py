@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     import re
     text = open(os.path.join(ROOT, "include", "cimbar_ingest.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(cimbar_(?:ingest|png)_[a-z_]+)\s*\(", text)))
+    declared = sorted(set(re.findall(r"\b(cimbar_(?:ingest|png|jpeg|image)_[a-z_]+)\s*\(", text)))
     assert declared == sorted(ingest.EXPORTS)
     L = ingest.load_library()
     for name in declared:
