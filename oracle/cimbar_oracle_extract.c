@@ -44,13 +44,16 @@ int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out)
 	const size_t n = (size_t)w * h;
 	unsigned unit = (unsigned)(w < h ? w : h);
 	unit = next_pow2_plus_one((unsigned)(unit * 0.002));
-	if (unit != 3 && unit != 5 && unit != 9) return -1;   /* (17 and up: captures of 4500 px and more on the short side) */
+	if (unit != 3 && unit != 5 && unit != 9 && unit != 17) return -1;   /* (33 and up: captures of 8500 px and more on the short side) */
 	/* ksize 9: getGaussianKernel(9, sigma <= 0) -> sigma = 0.3*((9-1)*0.5 - 1) + 0.8 = 1.7, exp(-x^2 / (2 sigma^2)) normalised, then the 8.8 fixed-point
  * weights of getGaussianKernelFixedPoint_ED (round outside-in with the error carried, centre = 256 - the rest): 256 * k = 3.80 12.75 30.29 50.90
  * 60.51 -> {4, 13, 30, 51, 60, 51, 30, 13, 4} (plain rounding gives the same, no value is near a half), s = 16 [assumed-OpenCV] */
+	/* ksize 17: sigma = 0.3*((17-1)*0.5 - 1) + 0.8 = 2.9; 256 * k = 0.786 1.919 4.156 7.992 13.647 20.691 27.853 33.292 35.331; rounded outside-in with the
+	 * error carried: 1 2 4 8 13 21 28 33, centre 256 - 2 * 110 = 36 (the fifth weight is 13.4993 before rounding) [assumed-OpenCV] */
 	const int r = (int)unit / 2, shift = r == 1 ? 4 : (r == 2 ? 8 : 16);
-	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
-	const int* k = r == 1 ? k3 : (r == 2 ? k5 : k9);
+	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4},
+	                 k17[17] = {1, 2, 4, 8, 13, 21, 28, 33, 36, 33, 28, 21, 13, 8, 4, 2, 1};
+	const int* k = r == 1 ? k3 : (r == 2 ? k5 : (r == 4 ? k9 : k17));
 
 	uint8_t* gray = (uint8_t*)malloc(n);
 	int* hs = (int*)malloc(n * sizeof(int));

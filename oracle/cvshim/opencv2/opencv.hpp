@@ -630,15 +630,18 @@ inline double invert(const Mat& src_, Mat& dst, int method)
 // pass in 16 bit, vertical pass in 32 bit, one final rounding): dst = (sum_ij w_i w_j p + 2^(s-1)) >> s with integer weights
 // summing to 2^s (s = 4 | 8). BORDER_DEFAULT = BORDER_REFLECT_101. ksize 9: getGaussianKernel(9, sigma <= 0) -> sigma = 0.3*((9-1)*0.5 - 1) + 0.8 = 1.7, exp(-x^2 / (2 sigma^2)) normalised, then the 8.8 fixed-point
 // weights of getGaussianKernelFixedPoint_ED (round outside-in with the error carried, centre = 256 - the rest): 256 * k = 3.80 12.75 30.29 50.90
-// 60.51 -> {4, 13, 30, 51, 60, 51, 30, 13, 4} (plain rounding gives the same, no value is near a half), s = 16.
+// 60.51 -> {4, 13, 30, 51, 60, 51, 30, 13, 4} (plain rounding gives the same, no value is near a half), s = 16. ksize 17 (captures of 4500 px and
+// more on the short side): sigma = 2.9, 256 * k = 0.786 1.919 4.156 7.992 13.647 20.691 27.853 33.292 35.331 -> with the error carried
+// outside-in {1, 2, 4, 8, 13, 21, 28, 33, 36, ...} (the fifth weight is 13.4993 before rounding: 0.0007 below the boundary), s = 16.
 inline void GaussianBlur(const Mat& src_, Mat& dst, Size ksize, double, double = 0)
 {
-	if (src_.type() != CV_8UC1 || ksize.width != ksize.height || (ksize.width != 3 && ksize.width != 5 && ksize.width != 9))
-	{ std::cerr << "cv-shim: GaussianBlur: CV_8UC1 with ksize 3, 5 or 9 only" << std::endl; std::abort(); }
+	if (src_.type() != CV_8UC1 || ksize.width != ksize.height || (ksize.width != 3 && ksize.width != 5 && ksize.width != 9 && ksize.width != 17))
+	{ std::cerr << "cv-shim: GaussianBlur: CV_8UC1 with ksize 3, 5, 9 or 17 only" << std::endl; std::abort(); }
 	Mat src = src_.clone();
 	const int W = src.cols, H = src.rows, r = ksize.width / 2;
-	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
-	const int* k = r == 1 ? k3 : (r == 2 ? k5 : k9);
+	static const int k3[3] = {1, 2, 1}, k5[5] = {1, 4, 6, 4, 1}, k9[9] = {4, 13, 30, 51, 60, 51, 30, 13, 4},
+	                 k17[17] = {1, 2, 4, 8, 13, 21, 28, 33, 36, 33, 28, 21, 13, 8, 4, 2, 1};
+	const int* k = r == 1 ? k3 : (r == 2 ? k5 : (r == 4 ? k9 : k17));
 	const int shift = r == 1 ? 4 : (r == 2 ? 8 : 16);
 	auto refl = [](int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; };
 	std::vector<int> h((size_t)W * H);

@@ -109,7 +109,8 @@ def test_extract_stage_bad_arguments(hip_decoder):
 
 @pytest.mark.parametrize("size,quad", [((1280, 720), ((300, 10), (990, 20), (290, 700), (1000, 690))),
                                         ((3840, 2160), ((900, 60), (2950, 100), (880, 2090), (2980, 2050))),
-                                        ((4000, 2600), ((800, 70), (3300, 120), (780, 2500), (3340, 2460)))])   # short side >= 2500 px: 9x9 blur
+                                        ((4000, 2600), ((800, 70), (3300, 120), (780, 2500), (3340, 2460))),      # short side >= 2500 px: 9x9 blur
+                                        ((5600, 4600), ((600, 90), (4900, 160), (560, 4480), (4960, 4400)))])     # short side >= 4500 px: 17x17 blur
 def test_other_capture_sizes_match_oracle(hip_decoder, synth, oracle, size, quad):
     """720p (3x3 blur, the warp upscales) and 2160p (5x5 blur, the warp shrinks): both passes against the oracle, corners from the quad"""
     w, h = size
@@ -190,15 +191,17 @@ def test_scan_extract_decode_chain_equals_the_reference_chain(hip_decoder, synth
             assert masks[k] == wmask and (chunks[k] == wchunks).all(), (pre, k)
 
 
-def test_extract_of_a_capture_that_needs_the_9x9_blur(hip_decoder, synth, oracle):
-    """a 4000x2600 capture (Scanner's blur unit 9, Scanner.h:157-159) through the whole of Extractor::extract and on through the decoder"""
+@pytest.mark.parametrize("w,h,quad", [(4000, 2600, ((800, 70), (3300, 120), (780, 2500), (3340, 2460))), (5600, 4600, ((600, 90), (4900, 160), (560, 4480), (4960, 4400)))],
+                         ids=["9x9-blur", "17x17-blur"])
+def test_extract_of_a_capture_that_needs_the_larger_blurs(hip_decoder, synth, oracle, w, h, quad):
+    """captures of 2500 px / 4500 px and more on the short side (Scanner's blur unit 9 / 17, Scanner.h:157-159) through the whole of
+    Extractor::extract and on through the decoder"""
     payload, frames = F.clean_frames(synth, 1, seed=78)
-    quad = ((800, 70), (3300, 120), (780, 2500), (3340, 2460))
-    cam = np.ascontiguousarray(F.camera_frame(frames[0], width=4000, height=2600, quad=quad, background=8))
+    cam = np.ascontiguousarray(F.camera_frame(frames[0], width=w, height=h, quad=quad, background=8))
     status, corners, out = hip_decoder.extract_batch(cam[None])
     want = np.zeros((1024, 1024, 3), np.uint8)
     c8 = (ctypes.c_float * 8)()
-    st = oracle.co_extract(P(cam), 4000, 2600, P(want), c8)
+    st = oracle.co_extract(P(cam), w, h, P(want), c8)
     assert status[0] == st == 1 and list(corners[0]) == list(c8) and (out[0] == want).all()
     hip_decoder.reset_ccm()
     total, chunks, masks, st2 = hip_decoder.scan_extract_decode_batch(cam[None])

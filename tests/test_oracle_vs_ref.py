@@ -190,7 +190,8 @@ def test_random_distortions_oracle_equals_reference(ref, synth, seed):
 
 @pytest.mark.parametrize("size,quad", [((1280, 720), ((300, 10), (990, 20), (290, 700), (1000, 690))),
                                         ((3840, 2160), ((900, 60), (2950, 100), (880, 2090), (2980, 2050))),
-                                        ((4000, 2600), ((800, 70), (3300, 120), (780, 2500), (3340, 2460)))])   # short side >= 2500 px: 9x9 blur
+                                        ((4000, 2600), ((800, 70), (3300, 120), (780, 2500), (3340, 2460))),      # short side >= 2500 px: 9x9 blur
+                                        ((5600, 4600), ((600, 90), (4900, 160), (560, 4480), (4960, 4400)))])     # short side >= 4500 px: 17x17 blur
 def test_extractor_stage_other_capture_sizes(ref, oracle, synth, size, quad):
     """720p (3x3 blur, heavy downscale) and 2160p (5x5 blur): preprocessing and warp of the oracle against the reference build"""
     w, h = size
