@@ -1,7 +1,7 @@
 """GPU: the batch-parallel flood's certificate (k_flood_wave: "no tie-break of the reference's heap could have changed this frame's result")
 checked against the exact replay on ~100 000 distorted frames in three geometries, GPU vs GPU, through the library's own verify mode
 (CIMBAR_HIP_FLOOD_VERIFY=1: every certified frame is replayed exactly and compared cell by cell, CIMBAR_HIP_TAP_FLOOD_VERIFY) -- and the
-exact replay's kernel variants (k_flood3 with six- / five-level pops, k_flood2) against each other and the oracle."""
+exact replay's kernels (k_flood3, k_flood2, k_flood) against each other and the oracle."""
 import os
 
 import numpy as np
@@ -112,7 +112,7 @@ def camera_like(synth, n, seed):
 
 
 def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
-    """k_flood3 (six- and five-level pops), k_flood2 and the one-wavefront k_flood on shifted, noisy, rescaled, pure-noise and camera-like
+    """k_flood3, k_flood2 and the one-wavefront k_flood on shifted, noisy, rescaled, pure-noise and camera-like
     frames, every flagged frame through the exact replay; two of the camera-like frames also against the oracle (the others GPU vs GPU)"""
     payload, fr = F.clean_frames(synth, 6, seed=606)
     g = np.random.default_rng(66)
@@ -122,7 +122,7 @@ def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
     frames = np.ascontiguousarray(np.stack(frames))
     n = len(frames)
     outs = {}
-    for name, env in (("flood3-6", {}), ("flood3-5", {"CIMBAR_HIP_FLOOD_LV6": "0"}), ("flood2", {"CIMBAR_HIP_FLOOD3": "0"}), ("flood1", {"CIMBAR_HIP_FLOOD2": "0"})):
+    for name, env in (("flood3", {}), ("flood2", {"CIMBAR_HIP_FLOOD3": "0"}), ("flood1", {"CIMBAR_HIP_FLOOD2": "0"})):
         dec = decoder_with(dict(env, CIMBAR_HIP_FLOOD_WAVE="0"))
         for pre in (0, 1):
             dec.reset_ccm()
@@ -132,7 +132,7 @@ def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
     for pre in (0, 1):
         ref = outs[("flood1", pre)]
         assert (ref[4][:7] == 1).all()
-        for name in ("flood3-6", "flood3-5", "flood2"):
+        for name in ("flood3", "flood2"):
             o = outs[(name, pre)]
             for k in range(n):
                 assert (o[2][k] == ref[2][k]).all(), f"{name} pre {pre} frame {k}: {(o[2][k] != ref[2][k]).sum()} symbols differ from the one-wavefront replay"
@@ -142,14 +142,14 @@ def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
     # the camera-like frames against the oracle (sharpened, as the extractor's NEEDS_SHARPEN verdict would have it)
     from libcimbar_amd import modeb
     xy = modeb.cell_positions()
-    o = outs[("flood3-6", 1)]
+    o = outs[("flood3", 1)]
     for k in (7, 8):
         pyref.oracle_decode(frames[k], 1, 2, pyref.CoCcm())
         wsym, wcol, wpos = pyref.oracle_stage()
         assert (o[2][k] == wsym).all() and (xy + o[3][k].astype(np.int32) == wpos).all(), f"camera-like frame {k} differs from the oracle"
 
 
-@pytest.mark.parametrize("env", [{}, {"CIMBAR_HIP_FLOOD_LV6": "0"}, {"CIMBAR_HIP_FLOOD3": "0"}], ids=["flood3-6", "flood3-5", "flood2"])
+@pytest.mark.parametrize("env", [{}, {"CIMBAR_HIP_FLOOD3": "0"}], ids=["flood3", "flood2"])
 def test_exact_replay_kernels_with_the_heap_spilling(synth, env):
     from libcimbar_amd import build as hipbuild
     from tests.test_gpu_flood import check, flood_frames
