@@ -71,8 +71,9 @@ def build_ingest(force=False, verbose=False):
 
 
 def build_spilltest(force=False, verbose=False):
-    """The test-only variant whose flood heap keeps 1024 slots in LDS (everything deeper goes through the spill path)."""
-    return build_hip(force, verbose, OUT_SPILLTEST, ("CIMBAR_HEAP_LDS=1024",))
+    """The test-only variant whose flood heap keeps 1024 slots in LDS (everything deeper goes through the spill path) and whose anchor search keeps
+    ONE hit per scan row (so that ordinary captures overflow the fast kernels' lists and take the serial slow path, k_scan_serial)."""
+    return build_hip(force, verbose, OUT_SPILLTEST, ("CIMBAR_HEAP_LDS=1024", "CIMBAR_SCAN_TINY_LISTS"))
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 captures, against the oracle's restatement (bit-exact), and the whole chain capture -> GPU preprocess -> [reference Scanner on the
 host] -> GPU deskew -> GPU decode against the reference's Extractor + Decoder. Parity with a real OpenCV is unpinned."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -132,10 +133,26 @@ def test_other_capture_sizes_match_oracle(hip_decoder, synth, oracle, size, quad
     assert (desk[0] == wantd).all()
 
 
-def test_extract_batch_matches_oracle_on_captures_that_work_and_that_fail(hip_decoder, synth, oracle):
+@pytest.fixture(scope="module")
+def tiny_list_decoder():
+    """the test build of the library (libcimbar_hip_spilltest.so, -DCIMBAR_SCAN_TINY_LISTS): the anchor search keeps ONE hit per scan row, so
+    any capture with two anchors on a row overflows the fast kernels' lists and goes through the serial slow path (k_scan_serial)"""
+    from libcimbar_amd import build as hipbuild
+    assert os.path.exists(hipbuild.OUT_SPILLTEST), "build it with `python -m libcimbar_amd.build` (or __graft_entry__.build())"
+    d = D.HipDecoder(0, lib_path=hipbuild.OUT_SPILLTEST)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("which", ["fast", "serial-slow-path"])
+def test_extract_batch_matches_oracle_on_captures_that_work_and_that_fail(hip_decoder, tiny_list_decoder, synth, oracle, which):
     """Extractor::extract entirely on the device (anchor search included): status, corners and deskewed frames == the oracle's co_extract
-    (itself pinned to the reference's Scanner / Extractor in tests/test_oracle_vs_ref.py), per capture size"""
+    (itself pinned to the reference's Scanner / Extractor in tests/test_oracle_vs_ref.py), per capture size -- through the fast kernels, and
+    with their lists shrunk to one entry so that the search overflows and k_scan_serial (Scanner::scan on one lane, lists in global memory)
+    has to produce the same answers"""
     from tests.test_oracle_vs_ref import scan_cases
+    if which != "fast":
+        hip_decoder = tiny_list_decoder
     cams = scan_cases(synth)
     by_size = {}
     for k, cam in enumerate(cams):

@@ -24,7 +24,7 @@ PY
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE WRITE_SIZE"; do
+           "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
 done
@@ -49,7 +49,7 @@ for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"
             e = d.setdefault(row["Counter_Name"], [0.0, 0])
             e[0] += float(row["Counter_Value"]); e[1] += 1
 res = {k: {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()} | {"dispatches": max(v[1] for v in d.values())} for k, d in acc.items()}
-json.dump({"per_dispatch_average": res, "note": "tools/config5_bench.py under rocprofv3 --pmc (three passes): 256 and 1024 captures of 1920x1080; grid = threads per launch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE counts 64 B per 128-B request on gfx950: x2 for bytes)"}, open(dst, "w"), indent=1)
+json.dump({"per_dispatch_average": res, "note": "tools/config5_bench.py under rocprofv3 --pmc (four passes): 256 and 1024 captures of 1920x1080; grid = threads per launch; FETCH_SIZE / WRITE_SIZE (own passes) in KiB (FETCH_SIZE counts 64 B per 128-B request on gfx950: x2 for bytes)"}, open(dst, "w"), indent=1)
 print(json.dumps(res)[:3000])
 PY
 rm -rf $OUT
