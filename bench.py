@@ -66,7 +66,7 @@ def measured_traffic(kernel, n):
     try:
         pmc = json.load(open(files[-1]))["pmc"]
         key = {"threshold": "k_threshold<2, false>", "symbols": "k_symbols", "rs_symbols": "k_rs<4>", "rs_colors": "k_rs<2>",
-               "colors": "k_colors", "frame_mid": "k_frame_mid", "frame_end": "k_frame_end", "flood": "k_flood"}[kernel]
+               "colors": "k_colors", "frame_mid": "k_frame_mid", "frame_end": "k_frame_end", "flood": "k_flood3"}[kernel]
         c = pmc[key]
         per_1024 = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         return per_1024 * n / 1024.0, os.path.basename(files[-1])

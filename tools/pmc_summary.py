@@ -18,8 +18,8 @@ def ours(name):
 
 
 def short(name):
-    for k in ("k_threshold<2, false>", "k_threshold<3, true>", "k_rs<4>", "k_rs<2>", "k_symbols", "k_flood_wave", "k_flood<10240>", "k_flood<7104>", "k_flood", "k_frame_mid", "k_colors",
-              "k_frame_end", "k_carry_out", "k_plane_bytes", "k_flood_wave", "k_flood<10240>", "k_flood<7104>"):
+    for k in ("k_threshold<2, false>", "k_threshold<3, true>", "k_rs<4>", "k_rs<2>", "k_symbols", "k_flood_wave", "k_flood3", "k_flood2", "k_flood", "k_frame_mid", "k_colors",
+              "k_frame_end", "k_carry_out", "k_count_flagged", "k_plane_bytes"):
         if k in name:
             return k
     return name[:60]
