@@ -167,7 +167,7 @@ int cimbar_hip_encode_batch(cimbar_hip_ctx* ctx, const uint8_t* payload, int n, 
  * stay in device memory for cimbar_hip_decode_batch. Any width x height RGB8 capture (densely packed frames); OpenCV's arithmetic is restated,
  * see DESIGN.md.
  *   cimbar_hip_scan_preprocess : n captures -> n * width * height bytes (0 / 255) = Scanner::preprocess_image(img, fast = true);
- *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Blur unit as in Scanner.h:157-159 (3x3 below 1500 px on the short side, 5x5 below 2500, 9x9 below 4500); 4500 px and more: EDIM.
+ *                                thresholds (n ints, may be NULL) receives the Otsu thresholds. Blur unit as in Scanner.h:157-159 (3x3 below 1500 px on the short side, 5x5 below 2500, 9x9 below 4500, 17x17 below 8500); 8500 px and more: EDIM.
  *   cimbar_hip_deskew_batch    : corners = n * 8 floats in HOST memory, per capture top-left, top-right, bottom-left, bottom-right (x, y)
  *                                exactly as Corners::all() returns them (Corners.h:45-53); frames = n * 1024*1024*3 bytes = what
  *                                Deskewer(0, {1024,1024}, 30).deskew(img, corners) returns.
@@ -179,8 +179,9 @@ int cimbar_hip_deskew_batch(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
 
 /* Extractor::extract (src/lib/extractor/Extractor.h:29-45) for n captures, entirely on the device: Scanner (image preparation AND the
  * anchor search: Scanner.h:277-405, Scanner.cpp:52-202, ScanState.h:21-104) -> Corners (Corners.h:45-73) -> Deskewer::deskew.
- *   status  : n ints, Extractor::FAILURE 0 / SUCCESS 1 / NEEDS_SHARPEN 2 (Extractor.h:18-20); -1 = one of the search's fixed-size work
- *             lists overflowed (hundreds of anchor-like patterns on one scan line), treated as a failure
+ *   status  : n ints, Extractor::FAILURE 0 / SUCCESS 1 / NEEDS_SHARPEN 2 (Extractor.h:18-20). A capture whose anchor search overflows the fast
+ *             kernels' fixed-size work lists (hundreds of anchor-like patterns on one scan line) is searched again serially with lists of
+ *             16 384 entries (up to 16 such captures per batch); -1 = those overflowed too, treated as a failure
  *   corners : n * 8 floats, Corners::all() (top-left, top-right, bottom-left, bottom-right; x, y); may be NULL. Unset where status <= 0
  *   frames  : n * 1024*1024*3 bytes, black where status <= 0
  * status / corners / frames share out_mem. Buffers, stream and errors as for cimbar_hip_decode_batch. */
