@@ -29,7 +29,7 @@ CASES = [(1, 120000, 3, 60, 0), (2, 120000, 12, 30, 0), (3, 80000, 1, 80, 0), (4
          (13, 60000, 1, 0, 64), (14, 60000, 64, 0, 500)]
 
 
-@pytest.mark.parametrize("levels", [5, 6])
+@pytest.mark.parametrize("levels", [5, 6, 7])      # 5: WaveHeap::pop, 6: pop6, 7: pop7 (six levels, one write per path node)
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"seed{c[0]}-prio{c[2]}-hover{c[4]}")
 def test_lane_parallel_heap_equals_libstdcxx(model, levels, case):
     seed, steps, prios, bias, hover = case

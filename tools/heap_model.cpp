@@ -59,6 +59,63 @@ struct WaveHeapModel {
 		for (auto& w : wr) H[w.first] = w.second;
 	}
 
+	// WaveHeap6::pop7 (the default since round 3): six levels per round like pop6, restated so that every node on the hole's path writes ONE slot
+	// -- its own: H'[c_k] = H[c_{k+1}] for k < j (the value of the child the path goes to, which the lane has fetched anyway), H'[c_j] = value --
+	// and so that the node with a left child only (stl_heap.h __adjust_heap's `(len & 1) == 0 && secondChild == (len - 2) / 2` case) is just a
+	// node that "prefers" its only child: no tail case, no parent writes across blocks, the root (the hole) is an ordinary path node.
+	uint32_t pop7()
+	{
+		const int len = n - 1;
+		if (len == 0) { n = 0; return 0u; }
+		const uint32_t value = H[len];
+		const uint32_t vprio = value >> 25;
+		uint32_t bchild[3][64]; int bg[3][64]; bool bp[3][64];
+		std::memset(bchild, 0, sizeof bchild); std::memset(bg, 0, sizeof bg); std::memset(bp, 0, sizeof bp);
+		int r0 = 0, j = 0;
+		bool cont = true;
+		uint32_t rootchild = 0;
+		for (int B = 0; B < 3 && cont; ++B) {
+			int gi[64]; uint32_t v[64], vl[64], vr[64];
+			uint64_t right = 0, contm = 0;
+			for (int lane = 0; lane < 64; ++lane) {
+				const int d = 31 - clz32((unsigned)lane + 1u);
+				gi[lane] = lane < 63 ? (r0 << d) + lane : 0x40000000;
+				const long cl = 2L * gi[lane] + 1;
+				const bool hasL = cl < len, inner = cl + 1 < len;
+				v[lane] = gi[lane] < (int)H.size() ? H[gi[lane]] : 0u;          // (unconditional reads; out-of-range ones are never used)
+				vl[lane] = cl < (long)H.size() ? H[cl] : 0u;
+				vr[lane] = cl + 1 < (long)H.size() ? H[cl + 1] : 0u;
+				if (inner && (vr[lane] >> 25) <= (vl[lane] >> 25)) right |= 1ull << lane;
+				if (hasL) contm |= 1ull << lane;
+			}
+			uint64_t pm = 0, cm = 0;
+			for (int lane = 0; lane < 63; ++lane) {
+				const bool onp = (((right ^ dirm[lane]) & ancm[lane]) | (~contm & ancm[lane])) == 0;
+				if (onp) pm |= 1ull << lane;
+				if (onp && (v[lane] >> 25) <= vprio) cm |= 1ull << lane;
+				bg[B][lane] = gi[lane]; bp[B][lane] = onp;
+				bchild[B][lane] = ((right >> lane) & 1ull) ? vr[lane] : vl[lane];
+			}
+			if (B == 0) rootchild = bchild[0][0];
+			if (cm) j = 6 * B + (31 - clz32((unsigned)(63 - clz64(cm)) + 1u));
+			const int last = 63 - clz64(pm);                               // pm is never empty: the block's root is on the path
+			if (last >= 31 && ((contm >> last) & 1ull)) r0 = 2 * gi[last] + 1 + (int)((right >> last) & 1ull);
+			else cont = false;
+		}
+		std::vector<std::pair<int, uint32_t>> wr;
+		for (int B = 0; B < 3; ++B)
+			for (int lane = 0; lane < 63; ++lane) {
+				const int dp = 6 * B + (31 - clz32((unsigned)lane + 1u));
+				if (bp[B][lane] && dp <= j) wr.push_back({bg[B][lane], dp < j ? bchild[B][lane] : value});
+			}
+		for (size_t a = 0; a < wr.size(); ++a)
+			for (size_t b = a + 1; b < wr.size(); ++b)
+				if (wr[a].first == wr[b].first) return 0xFFFFFFFFu;          // every slot at most once
+		for (auto& w : wr) { if (w.first < 0 || w.first >= len) return 0xFFFFFFFFu; H[w.first] = w.second; }
+		n = len;
+		return j == 0 ? value : rootchild;
+	}
+
 	// LV = levels per round: 5 = WaveHeap::pop, 6 = WaveHeap6::pop6. Returns what the kernel reports as the root afterwards (0 if empty;
 	// 0xFFFFFFFF if two of its scattered writes disagree about one slot).
 	uint32_t pop(int LV)
@@ -165,7 +222,7 @@ extern "C" long heap_model_fuzz(int LV, unsigned seed, int steps, int max_prio, 
 		// pop
 		std::pop_heap(ref.begin(), ref.end(), Cmp());
 		ref.pop_back();
-		const uint32_t r = M.pop(LV);
+		const uint32_t r = LV == 7 ? M.pop7() : M.pop(LV);
 		if (r == 0xFFFFFFFFu) return -step;
 		if (M.n != (int)ref.size()) return step;
 		if (!ref.empty() && (std::memcmp(M.H.data(), ref.data(), ref.size() * 4) != 0 || r != ref[0])) return step;
