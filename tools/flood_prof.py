@@ -42,13 +42,29 @@ for kind in ("config5", "shift"):
         if rc < 0:
             print("tap 100 not available: not the FLOOD_PROF build"); sys.exit(1)
         path = dec.tap(7, n)
-        use = raw[raw[:, 6] > 0]
+        hw_h, hw_d = (raw[:, 6] >> np.uint64(32)).astype(np.int64), (raw[:, 14] >> np.uint64(32)).astype(np.int64)   # HW_ID of either wavefront
+        raw[:, 6] &= np.uint64(0xFFFFFFFF)
+        raw[:, 14] &= np.uint64(0xFFFFFFFF)
+        keep = raw[:, 6] > 0
+        use = raw[keep]
         steps = use[:, 6].astype(np.float64)
+        simd = lambda h: (h >> 4) & 3
+        slot = lambda h: h & 15
+        cu = lambda h: ((h >> 8) & 15) | (((h >> 12) & 1) << 4) | (((h >> 13) & 7) << 5)      # CU_ID | SH_ID | SE_ID (per XCC)
+        import collections
+        placement = collections.Counter((int(simd(a)), int(simd(b)), int(slot(a)), int(slot(b))) for a, b in zip(hw_h[keep], hw_d[keep]))
+        per_simd = collections.Counter()
+        for a in hw_h[keep]:
+            per_simd[(int(cu(a)), int(simd(a)))] += 1
+        h_share = collections.Counter(per_simd.values())          # how many heap owners share one SIMD of one (XCC-local) CU id
         H = {k: float((use[:, i] / steps).mean()) for k, i in (("handover", 0), ("pushes", 1), ("pop", 2), ("wait", 5))}
         Dv = {k: float((use[:, 8 + i] / use[:, 14].astype(np.float64)).mean()) for k, i in (("handover", 0), ("fetch", 3), ("decode_offers", 4), ("wait", 5))}
         row = {"frames": n, "ms": round(best * 1e3, 2), "exact_frames": int((path == 1).sum()), "areas_with_data": int(len(use)), "steps_per_frame": float(steps.mean()),
                "H_cycles_per_step": {k: round(v, 1) for k, v in H.items()}, "D_cycles_per_step": {k: round(v, 1) for k, v in Dv.items()},
-               "H_total": round(sum(H.values()), 1), "D_total": round(sum(Dv.values()), 1)}
+               "H_total": round(sum(H.values()), 1), "D_total": round(sum(Dv.values()), 1),
+               "own_stale_pops_per_frame": float(use[:, 7].mean()),
+               "placement_simdH_simdD_slotH_slotD": {str(k): v for k, v in placement.most_common(12)},
+               "heap_owners_per_(cu_id,simd)_histogram": {str(k): v for k, v in sorted(h_share.items())}}
         out[f"{kind}_{n}"] = row
         print(kind, n, json.dumps(row), flush=True)
         torch.cuda.empty_cache()

@@ -20,7 +20,7 @@ last = max(i for i, r in enumerate(rows) if "k_scan_stage1" in r[2])
 t0 = rows[last][0]
 for s, e, name, grid, q in rows[last:]:
     short = name.split("(")[0].split("::")[-1][:34]
-    if any(k in name for k in ("k_flood", "k_symbols", "k_threshold", "k_rs", "k_warp", "k_frame", "k_colors")):
+    if "k_" in name:
         print(f"{(s - t0) / 1e6:8.2f} -> {(e - t0) / 1e6:8.2f} ms  {short:36s} grid {grid:>9s} queue {q}")
 PY
 tail -2 $OUT/trace.log
