@@ -158,3 +158,54 @@ def test_exact_replay_kernels_with_the_heap_spilling(synth, env):
     frames = frames + camera_like(synth, 1, seed=608)
     check(dec, frames, names + ["camera-like"])
     dec.close()
+
+
+def test_the_certifying_pass_is_skipped_where_it_achieves_nothing_and_nothing_changes(synth):
+    """enqueue()'s scheduling heuristic: after a batch in which k_flood_wave certified (almost) none of the frames it was given, the following
+    batches go straight to the exact replay and every sixteenth probes again; a stream it does certify keeps it. Whatever it decides, chunks,
+    masks, symbols and drift are the ones CIMBAR_HIP_FLOOD_WAVE_ADAPT=0 produces."""
+    dev = torch.device("cuda", 0)
+    n = 256
+    payload, fr = F.clean_frames(synth, 4, seed=611)
+    g = np.random.default_rng(612)
+    base = torch.from_numpy(np.ascontiguousarray(fr)).to(dev)
+    base = base[torch.arange(n, device=dev) % 4].contiguous()
+    # what a deskewed capture looks like: a bilinear rescale by half a percent plus pixel noise (the certifier gives up on these in its first rounds)
+    h, w = base.shape[1:3]
+    theta = torch.tensor([[1.005, 0.0, 0.002], [0.0, 1.005, -0.001]], dtype=torch.float32, device=dev)
+    noisy = torch.empty_like(base)
+    for k in range(0, n, 64):
+        grid = torch.nn.functional.affine_grid(theta[None].expand(64, -1, -1), (64, 3, h, w), align_corners=False)
+        src = base[k:k + 64].permute(0, 3, 1, 2).to(torch.float32)
+        out = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="border", align_corners=False).permute(0, 2, 3, 1)
+        noisy[k:k + 64] = (out + torch.randn(out.shape, device=dev) * 20).round().clamp(0, 255).to(torch.uint8)
+        del grid, src, out
+    noisy = noisy.contiguous()
+    shifted = torch.roll(base, shifts=(2, 1), dims=(1, 2)).contiguous()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    outs = {}
+    for name, env in (("adaptive", {}), ("always", {"CIMBAR_HIP_FLOOD_WAVE_ADAPT": "0"})):
+        dec = decoder_with(env)
+        chunks = torch.zeros((n, dec.geo.FRAME_BYTES), dtype=torch.uint8, device=dev)
+        masks = torch.zeros((n,), dtype=torch.int32, device=dev)
+        rows = []
+        # 20 noisy batches (nothing certifies), then shifted ones (everything does): the probe after the skipped stretch must bring the pass back
+        for b in range(40):
+            src = noisy if b < 20 else shifted
+            dec.reset_ccm()
+            dec.decode_batch_device(src.data_ptr(), n, chunks.data_ptr(), masks.data_ptr(), False, 2, st)
+            torch.cuda.synchronize(dev)
+            path = dec.tap(D.TAP_FLOOD_PATH, n)
+            rows.append((chunks.cpu().numpy().copy(), masks.cpu().numpy().copy(), dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), path))
+        outs[name] = rows
+        dec.close()
+    for b in range(40):
+        a, r = outs["adaptive"][b], outs["always"][b]
+        assert (a[0] == r[0]).all() and (a[1] == r[1]).all() and (a[2] == r[2]).all(), f"batch {b}: results depend on the scheduling heuristic"
+        flagged = r[4] != 0
+        assert (a[3][flagged] == r[3][flagged]).all(), f"batch {b}: drift differs"
+    assert all((outs["always"][b][4] == 1).mean() > 0.9 for b in range(20)), "the noisy frames were meant to defeat the certifier"
+    assert all((outs["always"][b][4] == 2).all() for b in range(20, 40))
+    certified = [int((outs["adaptive"][b][4] == 2).sum()) for b in range(40)]
+    assert sum(certified[20:]) > 0 and certified[-1] == n, f"the pass never came back for the frames it certifies: {certified}"
+    assert sum(1 for b in range(20, 40) if certified[b] == n) >= 3

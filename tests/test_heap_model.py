@@ -26,10 +26,12 @@ def model(tmp_path_factory):
 # past 2^16 entries (three six-level rounds, four five-level ones)
 CASES = [(1, 120000, 3, 60, 0), (2, 120000, 12, 30, 0), (3, 80000, 1, 80, 0), (4, 150000, 20, 40, 0), (5, 60000, 2, 95, 0), (6, 100000, 6, 50, 0),
          (7, 60000, 4, 0, 3), (8, 60000, 9, 0, 30), (9, 60000, 2, 0, 62), (10, 80000, 13, 0, 2046), (11, 80000, 3, 0, 4094), (12, 80000, 5, 0, 9000),
-         (13, 60000, 1, 0, 64), (14, 60000, 64, 0, 500)]
+         (13, 60000, 1, 0, 64), (14, 60000, 64, 0, 500), (15, 200000, 7, 0, 32760), (16, 100000, 3, 0, 16380)]
 
 
-@pytest.mark.parametrize("levels", [5, 6, 7])      # 5: WaveHeap::pop, 6: pop6, 7: pop7 (six levels, one write per path node)
+# 5: WaveHeap::pop, 6: pop6, 7: pop7 (six levels, one write per path node), 8: pop7 + push4 (a burst's pushes four at a time, one gather and
+# one scatter; seed 15 hovers where push4 hands over to the one-by-one push because an entry could have more than 14 ancestors)
+@pytest.mark.parametrize("levels", [5, 6, 7, 8])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"seed{c[0]}-prio{c[2]}-hover{c[4]}")
 def test_lane_parallel_heap_equals_libstdcxx(model, levels, case):
     seed, steps, prios, bias, hover = case

@@ -15,13 +15,15 @@ for path in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recu
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size", "?"), r.get("Queue_Id", "?")))
 rows.sort()
-# the last batch: from the last k_scan_otsu on
-last = max(i for i, r in enumerate(rows) if "k_scan_stage1" in r[2])
-t0 = rows[last][0]
-for s, e, name, grid, q in rows[last:]:
-    short = name.split("(")[0].split("::")[-1][:34]
-    if "k_" in name:
-        print(f"{(s - t0) / 1e6:8.2f} -> {(e - t0) / 1e6:8.2f} ms  {short:36s} grid {grid:>9s} queue {q}")
+# every dispatch of the run that is one of ours and takes more than 20 us, relative to the first one (the warm-up batch comes first, then the timed
+# batch, then the extract-only batch)
+import re
+t0 = rows[0][0]
+for s, e, name, grid, q in rows:
+    short = re.sub(r"\(anonymous namespace\)::", "", name)
+    short = re.sub(r"^void ", "", short).split("(")[0][:40]
+    if "k_" in name and e - s > 20000:
+        print(f"{(s - t0) / 1e6:9.2f} -> {(e - t0) / 1e6:9.2f} ms ({(e - s) / 1e6:7.3f})  {short:42s} grid {grid:>9s} queue {q}")
 PY
 tail -2 $OUT/trace.log
 rm -rf $OUT

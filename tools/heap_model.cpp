@@ -59,6 +59,48 @@ struct WaveHeapModel {
 		for (auto& w : wr) H[w.first] = w.second;
 	}
 
+	// WaveHeap7::push4: up to four pushes of ONE priority with one gather and one scatter. std::push_heap only touches the ancestors of the
+	// new last element, so appending all k entries first and then sifting them up in order is the same sequence of heap states. Lane
+	// (g, t) = 16 g + t keeps the CURRENT value of node a(g,t) = ((n + g + 1) >> t) - 1, the level-t ancestor of entry g's slot (t = 0: the
+	// slot itself), through the k sift-ups: sift-up p moves the values on ITS path down by one as far as level m_p (the first ancestor whose
+	// current priority is not greater stops it) and puts e_p there; every lane whose node lies on that path -- in whatever group -- takes its
+	// new value from the lane above it in its own group (which tracks the same parent). Needs n >= 4 (no entry's ancestor is another new
+	// entry) and n + k <= 32767 (an entry has at most 14 ancestors): the caller pushes one by one otherwise.
+	void push4(const uint32_t* e, int k)
+	{
+		const uint32_t ed = e[0] >> 25;
+		int a[64], dc[64]; uint32_t cur[64], orig[64]; bool on[64];
+		for (int lane = 0; lane < 64; ++lane) {
+			const int g = lane >> 4, t = lane & 15;
+			const unsigned pos1 = (unsigned)(n + g) + 1u;
+			const int depth = 31 - clz32(pos1);
+			on[lane] = g < k && t <= depth;
+			a[lane] = (int)(pos1 >> t) - 1;
+			dc[lane] = depth - t;
+			cur[lane] = t == 0 ? e[g < k ? g : 0] : get(a[lane], on[lane]);
+			orig[lane] = cur[lane];
+		}
+		for (int p = 0; p < k; ++p) {
+			const unsigned pos1 = (unsigned)(n + p) + 1u;
+			const int depth = 31 - clz32(pos1);
+			uint64_t stop = 0;
+			for (int lane = 16 * p + 1; lane < 16 * p + 16; ++lane)
+				if (on[lane] && (cur[lane] >> 25) <= ed) stop |= 1ull << (lane - 16 * p);
+			const int m = stop ? __builtin_ctzll(stop) - 1 : depth;
+			uint32_t nxt[64];
+			for (int lane = 0; lane < 64; ++lane) {
+				const uint32_t up = (lane & 15) < 15 ? cur[lane + 1] : 0u;        // row_shl:1 (the lane above in the same group)
+				const int kk = depth - dc[lane];                                  // the level of path p at this node's depth
+				const bool onpath = on[lane] && kk >= 0 && kk <= m && (int)(pos1 >> kk) - 1 == a[lane];
+				nxt[lane] = onpath ? (kk < m ? up : e[p]) : cur[lane];
+			}
+			std::memcpy(cur, nxt, sizeof cur);
+		}
+		for (int lane = 0; lane < 64; ++lane)
+			if (on[lane] && ((lane & 15) == 0 || cur[lane] != orig[lane])) H[a[lane]] = cur[lane];
+		n += k;
+	}
+
 	// WaveHeap6::pop7 (the default since round 3): six levels per round like pop6, restated so that every node on the hole's path writes ONE slot
 	// -- its own: H'[c_k] = H[c_{k+1}] for k < j (the value of the child the path goes to, which the lane has fetched anyway), H'[c_j] = value --
 	// and so that the node with a left child only (stl_heap.h __adjust_heap's `(len & 1) == 0 && secondChild == (len - 2) / 2` case) is just a
@@ -222,7 +264,7 @@ extern "C" long heap_model_fuzz(int LV, unsigned seed, int steps, int max_prio, 
 		// pop
 		std::pop_heap(ref.begin(), ref.end(), Cmp());
 		ref.pop_back();
-		const uint32_t r = LV == 7 ? M.pop7() : M.pop(LV);
+		const uint32_t r = LV >= 7 ? M.pop7() : M.pop(LV);
 		if (r == 0xFFFFFFFFu) return -step;
 		if (M.n != (int)ref.size()) return step;
 		if (!ref.empty() && (std::memcmp(M.H.data(), ref.data(), ref.size() * 4) != 0 || r != ref[0])) return step;
@@ -236,12 +278,20 @@ extern "C" long heap_model_fuzz(int LV, unsigned seed, int steps, int max_prio, 
 		if (max_size && (long)ref.size() + burst > *max_size) *max_size = (long)ref.size() + burst;
 		const uint32_t ed = rng() % (uint32_t)max_prio;
 		uint32_t first = 0;
-		for (int q = 0; q < burst; ++q) {
-			const uint32_t e = entry(ed);
-			if (q == 0) first = e;
-			M.push(e);
-			ref.push_back(e);
-			std::push_heap(ref.begin(), ref.end(), Cmp());
+		for (int q = 0; q < burst;) {
+			// LV 8: pop7 and the pushes four at a time (push4) where its preconditions hold
+			const int k = (LV == 8 && M.n >= 4 && M.n + 4 <= 32767) ? std::min(4, burst - q) : 1;
+			uint32_t e[4];
+			for (int i = 0; i < k; ++i) {
+				e[i] = entry(ed);
+				if (q + i == 0) first = e[i];
+				ref.push_back(e[i]);
+				std::push_heap(ref.begin(), ref.end(), Cmp());
+			}
+			if (LV == 8 && k > 1) M.push4(e, k);
+			else if (LV == 8 && M.n >= 4 && M.n + 4 <= 32767 && (rng() & 1)) M.push4(e, 1);
+			else M.push(e[0]);
+			q += k;
 			if (M.n != (int)ref.size() || std::memcmp(M.H.data(), ref.data(), ref.size() * 4) != 0) return step;
 		}
 		if (!ref.empty()) {
