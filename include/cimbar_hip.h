@@ -266,7 +266,10 @@ enum {
 	CIMBAR_HIP_TAP_FLOOD_PATH = 7, /* n bytes         : 0 = parallel pass was exact, 1 = exact flood replay, 2 = certified batch flood */
 	CIMBAR_HIP_TAP_FLOOD_INFO = 8, /* n u32           : what the batch-parallel flood made of a flagged frame: low byte 0 = certified, 1..4 = the rule
 	                                  that declined it, 5 = out of super-rounds; bits 8..15 the super-round; bits 16.. cells decoded by then.
-	                                  0xFFFFFFFF for frames that were never flagged */
+	                                  0xFFFFFFFF for frames that were never flagged, and for every frame of a batch in which the pass did not
+	                                  run: after a batch where it certified fewer than one in sixteen of the frames it was given, the next fifteen
+	                                  batches go straight to the exact replay (CIMBAR_HIP_FLOOD_WAVE_ADAPT=0 at cimbar_hip_create: never skip).
+	                                  Which pass produced a frame's symbols never changes them */
 	CIMBAR_HIP_TAP_FLOOD_VERIFY = 9 /* n u32          : with CIMBAR_HIP_FLOOD_VERIFY=1 in the environment at cimbar_hip_create, every frame the batch-parallel
 	                                  flood certified is ALSO replayed exactly and compared: cells whose symbol or drifted position differed
 	                                  (0 = the certificate held; the exact result is what the decode used either way); 0xFFFFFFFF for frames

@@ -96,7 +96,7 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=No
         "extract_only_ms": round(best_ext * 1e3, 3), "extract_only_captures_per_s": round(n / best_ext, 1),
         "extracted": int((st > 0).sum()), "needs_sharpen": int((st == 2).sum()), "frames_fully_decoded": int(full.sum()),
         "payload_ok_where_decoded": payload_ok, "flood_exact_frames": int((path == 1).sum()), "flood_batch_frames": int((path == 2).sum()),
-        "flood_wave_outcome_by_rule": rules,
+        "flood_wave_outcome_by_rule": rules if seen.size else "certifying pass skipped by the scheduler for this batch (it certified < 1/16 of the batch before)",
         "flood_wave_declined_at": {"median_super_round": int(np.median((declined >> 8) & 0xFF)) if declined.size else None,
                                    "median_cells_decoded": int(np.median(declined >> 16)) if declined.size else None},
         "note": "device-resident 1080p captures -> cimbar_hip_scan_extract_decode_batch (blur, Otsu, anchor search, warp, decode), preprocess = guess"}}

@@ -65,8 +65,15 @@ class LibraryGather:
         self.dec, self.dev, self.group = dec, dev, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         from . import decoder as _d
-        box = [_d.comm_unique_id() if self.rank == 0 else None]
+        box = [None]
+        if self.rank == 0:
+            try:
+                box[0] = _d.comm_unique_id()
+            except Exception as e:          # (no RCCL for the library to bind: every rank must learn that, or the others wait in the broadcast forever)
+                box[0] = e
         dist.broadcast_object_list(box, src=0, group=group)
+        if isinstance(box[0], Exception):
+            raise RuntimeError(f"rank 0 could not create a communicator id: {box[0]!r}")
         self.comm = dec.comm_init_rank(box[0], self.world, self.rank)
         self.stream = torch.cuda.Stream(dev)
 

@@ -27,7 +27,8 @@ def build(tmp_path):
 def test_comm_init_all_with_one_device(tmp_path):
     exe = build(tmp_path)
     res = subprocess.run([str(exe), "1", "5", str(tmp_path / "template.bin")], capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0 and res.stdout.startswith("OK"), res.stdout + res.stderr
+    # (RCCL may print its version banner to stdout first, depending on the box's environment)
+    assert res.returncode == 0 and any(l.startswith("OK") for l in res.stdout.splitlines()), res.stdout + res.stderr
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process (the builder's boxes have one)")
@@ -36,4 +37,5 @@ def test_comm_init_all_gathers_across_every_gpu_of_the_node(tmp_path):
     ndev = min(torch.cuda.device_count(), 8)
     res = subprocess.run([str(exe), str(ndev), "64", str(tmp_path / "template.bin")], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert res.returncode == 0 and res.stdout.startswith("OK"), res.stdout + res.stderr
+    # (RCCL may print its version banner to stdout first, depending on the box's environment)
+    assert res.returncode == 0 and any(l.startswith("OK") for l in res.stdout.splitlines()), res.stdout + res.stderr
