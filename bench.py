@@ -450,6 +450,16 @@ def extras(dec, dev, stream, n, outs, steps):
         # the same at 1024 captures per batch: the exact flood keeps one (two-wavefront) workgroup per frame busy for ~35 ms whatever the batch,
         # so the per-batch time barely moves and throughput follows the batch size until every CU holds its four frames
         out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=1, key="config5_extract_1024"))
+        torch.cuda.empty_cache()
+        # and as a stream of batches through two / three contexts (the reference CLI's worker threads): extract and threshold of one batch run
+        # beside the flood replay of another
+        try:
+            out.update(extractbench.run_stream(dev, n=1024, contexts=2, batches=6, key="config5_stream_1024"))
+            torch.cuda.empty_cache()
+            out.update(extractbench.run_stream(dev, n=256, contexts=3, batches=12, key="config5_stream_256"))
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["config5_stream_1024"] = {"error": repr(e)}
     except ImportError:
         pass
     except Exception as e:

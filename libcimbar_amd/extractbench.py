@@ -100,3 +100,50 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=No
         "flood_wave_declined_at": {"median_super_round": int(np.median((declined >> 8) & 0xFF)) if declined.size else None,
                                    "median_cells_decoded": int(np.median(declined >> 16)) if declined.size else None},
         "note": "device-resident 1080p captures -> cimbar_hip_scan_extract_decode_batch (blur, Otsu, anchor search, warp, decode), preprocess = guess"}}
+
+
+def run_stream(dev, n=1024, contexts=2, batches=6, reps=2, key="config5_stream_1024"):
+    """BASELINE configs[4] as a STREAM of batches: `contexts` decoder contexts, each on its own HIP stream, take the batches in turn -- what the
+    reference's CLI does with one Decoder per worker thread (cimbar.cpp: each thread owns its Extractor + Decoder, so the colour-correction
+    carry-over is per worker there too). One batch's blur / anchor scan / warp / threshold then run while another batch's flood replay holds
+    the chip's wavefront slots only thinly. Same captures as run(); throughput over `batches` back-to-back batches."""
+    from .decoder import HipDecoder
+    boot = HipDecoder(dev.index or 0)
+    st0 = torch.cuda.current_stream(dev)
+    payload = framegen.synth_payload(n, seed=777, device=dev)
+    frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+    boot.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), st0.cuda_stream)
+    caps = make_captures(frames)
+    del frames
+    boot.close()
+    h, w = caps.shape[1:3]
+    decs = [HipDecoder(dev.index or 0) for _ in range(contexts)]
+    streams = [torch.cuda.Stream(dev) for _ in range(contexts)]
+    bufs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev),
+             torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(contexts)]
+    best = None
+    try:
+        for rep in range(reps + 1):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for b in range(batches):
+                k = b % contexts
+                c, m, s = bufs[k]
+                decs[k].scan_extract_decode_device(caps.data_ptr(), w, h, n, c.data_ptr(), m.data_ptr(), s.data_ptr(), -1, 2, streams[k].cuda_stream)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / batches
+            if rep > 0:
+                best = dt if best is None or dt < best else best
+        ok = True
+        full = 0
+        for c, m, s in bufs:
+            sel = m == 0xFFF
+            full = int(sel.sum().item())
+            ok = ok and bool((c[sel] == payload[sel]).all().item())
+    finally:
+        for d in decs:
+            d.close()
+    return {key: {"captures_per_batch": n, "contexts": contexts, "batches_timed": batches, "ms_per_batch": round(best * 1e3, 3), "captures_per_s": round(n / best, 1),
+                  "frames_fully_decoded_per_batch": full, "payload_ok_where_decoded": ok,
+                  "note": "a stream of batches through several decoder contexts on their own HIP streams (= the reference CLI's worker threads, one Decoder each): "
+                          "batch k+1's scan / extract / threshold overlap batch k's flood replay"}}
