@@ -126,8 +126,15 @@ def cases(frame=None, seed=7, big=True):
                 out.append((f"pillow_frame_l{lvl}", buf.getvalue(), frame))
     except ImportError:
         pass
+    # what cv::imwrite writes by default, i.e. the reference encoder's own files (imgcodecs grfmt_png.cpp: PNG_FILTER_SUB on every row,
+    # Z_BEST_SPEED, strategy Z_RLE): streams of short literal codes -- the inflate kernels' literal-burst path
+    for nm, im in (("crop", crop), ("noise", noise), ("black", black), ("grad", grad)):
+        out.append((f"{nm}_cvdefault", make_png(im, [1] * im.shape[0], level=1, strategy=zlib.Z_RLE), im))
+    out.append(("crop_sub_huff", make_png(crop, [1] * crop.shape[0], level=6, strategy=zlib.Z_HUFFMAN_ONLY), crop))   # literals only
+    out.append(("crop_sub_fixed", make_png(crop, [1] * crop.shape[0], level=1, strategy=zlib.Z_FIXED), crop))         # 8- and 9-bit literals
     if big:
         out.append(("frame_fmix", make_png(frame, g.integers(0, 5, frame.shape[0]), level=1), frame))
+        out.append(("frame_cvdefault", make_png(frame, [1] * frame.shape[0], level=1, strategy=zlib.Z_RLE), frame))
         fn = np.clip(frame.astype(np.int16) + g.normal(0, 30, frame.shape).astype(np.int16), 0, 255).astype(np.uint8)
         out.append(("frame_noisy", make_png(fn, g.integers(0, 5, fn.shape[0]), level=1), fn))
     return out

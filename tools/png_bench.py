@@ -20,9 +20,17 @@ host128 = fr.cpu().numpy()
 out = {}
 levels = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,6").split(",")]
 variant = os.environ.get("CIMBAR_HIP_PNG_SIMT", "0")
+writer = os.environ.get("PNG_WRITER", "pillow")        # pillow: adaptive filters; opencv: cv::imwrite's defaults (Sub filter, Z_RLE)
 for lvl, n in [(l, n) for l in levels] + [(1, 4 * n)]:
     pngs = []
     for k in range(128):
+        if writer == "opencv":
+            # what cv::imwrite writes by default, i.e. what the reference's encoder CLI produces (imgcodecs grfmt_png.cpp: PNG_FILTER_SUB on every
+            # row, Z_BEST_SPEED, strategy Z_RLE)
+            import zlib
+            from tests import png_cases
+            pngs.append(png_cases.make_png(host128[k], [1] * host128[k].shape[0], level=lvl, strategy=zlib.Z_RLE))
+            continue
         buf = io.BytesIO()
         Image.fromarray(host128[k]).save(buf, format="PNG", compress_level=lvl)
         pngs.append(buf.getvalue())
@@ -57,7 +65,7 @@ for lvl, n in [(l, n) for l in levels] + [(1, 4 * n)]:
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     ok = bool((d_status == 0).all().item()) and all(bool((d_rgb[i] == fr[i % 128]).all().item()) for i in range(0, n, 37))
-    out[f"kernels_level{lvl}_n{n}"] = {"simt": variant, "images": n, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1), "ok": ok, "rc": rc,
+    out[f"kernels_level{lvl}_n{n}"] = {"simt": variant, "writer": writer, "images": n, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1), "ok": ok, "rc": rc,
                                   "avg_zlib_bytes": int(sum(l for _o, l in offs) / 128)}
     print(json.dumps(out[f"kernels_level{lvl}_n{n}"]), flush=True)
     del d_scratch, d_rgb

@@ -288,11 +288,47 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 				if (sym < 256) {
 					if (o.op >= o.cap) return E_OUTSIZE;
 					const uint32_t before = o.op;
-					o.win[o.op & WMASK] = (uint8_t)sym;
-				g_stats[0]++;
-					o.op += 1;
+					const uint32_t l1 = br.insym ? br.bp - br.tokbase : 99u;
+					const int FB = CHUNK == 16 ? 7 : 8;           // k_png_inflate4's table is indexed by seven bits, k_png_inflate's by eight
+					if (l1 > (uint32_t)FB) {
+						o.win[o.op & WMASK] = (uint8_t)sym;
+						g_stats[0]++;
+						o.op += 1;
+						o.after(before);
+						continue;
+					}
+					// a literal burst (the kernels' fast_build + walk): every place of the turn's window where a short literal could start is
+					// looked up; the chain 0 -> len(0) -> ... is followed while it meets literals of <= 8 bits, up to the end of the image
+					const uint32_t limit = CHUNK == 16 ? 48u : 56u, room = o.cap - before;
+					uint32_t off = 0, cnt = 0;
+					while (off < limit && cnt < room) {
+						const uint32_t b = (uint32_t)(br.Rtok >> off) & ((1u << FB) - 1u);
+						uint32_t r8 = 0;
+						for (int i = 0; i < FB; ++i) r8 |= ((b >> i) & 1u) << (FB - 1 - i);
+						uint32_t f = 0;
+						for (int L = FB; L >= 1; --L) {
+							const uint32_t codeL = r8 >> (FB - L);
+							if (codeL - ll.first[L] < ll.count[L]) {
+								const uint32_t e = ll.sorted[(int32_t)codeL + ll.base[L]];
+								f = e < 256u ? ((uint32_t)L << 9) | e : 0u;
+							}
+						}
+						if (!f) break;
+						o.win[(before + cnt) & WMASK] = (uint8_t)f;
+						off += f >> 9;
+						++cnt;
+						g_stats[0]++;
+					}
+					if (cnt == 0) return E_MODEL;                  // (the first literal is a short one: the table must have it)
+					br.bp = br.tokbase + off;
+					if ((br.bp >> 5) > br.nwords + 2) br.overrun = true;
+					o.op = before + cnt;
 					o.after(before);
-					continue;
+					if (off > 16u) continue;
+					// the token behind the burst out of the same window, if it is a match
+					const uint32_t keep = br.bp;
+					if (canon_decode(ll, br, &sym) != PNG_OK) continue;       // (nothing consumed: the next turn reports it)
+					if (sym <= 256) { br.bp = keep; continue; }
 				}
 				if (sym == 256) { br.end_symbols(); break; }
 				if (sym > 285) return E_CODE;
