@@ -361,46 +361,62 @@ def extras(dec, dev, stream, n, outs, steps):
                                         "pcie_bytes_per_frame": int(ps["bytes_to_device"] / mm), "refused": ps["refused_by_host_walk"] + ps["refused_by_device"],
                                         "note": "PNG files -> cimbar_ingest_run_files in device PNG mode: compressed bytes over PCIe, k_png_inflate + "
                                                 "k_png_unfilter + decode on the device (up to 3 batches of 4096 in flight: the four-streams-per-wavefront inflate)"}
-            # the two PNG kernels alone on device-resident streams
+            # the two PNG kernels alone on device-resident streams, for the two kinds of PNG a frame comes as: Pillow's writer (adaptive
+            # filters, deflate level 1: long matches) and cv::imwrite's defaults, i.e. the reference encoder's own files (Sub filter on every
+            # row, Z_RLE, level 1: mostly 2-bit literals -- five times the tokens)
             from libcimbar_amd import decoder as _d
             import ctypes as _ct
-            npng = 8192
-            desc = (_d.PngDesc * npng)()
-            blob, offs = bytearray(), []
-            for k in range(128):
-                w_, h_, ct_, _dp, _il, z, _pal = _d.png_split(open(paths[k], "rb").read())
+            import struct as _st, zlib as _zl
+            L = _d.load_library()
+
+            def cv_default_zlib(img):
+                rows = img.reshape(img.shape[0], -1).astype(np.int16)
+                sub = rows.copy()
+                sub[:, 3:] -= rows[:, :-3]
+                raw = np.concatenate([np.ones((img.shape[0], 1), np.uint8), (sub & 0xFF).astype(np.uint8)], axis=1).tobytes()
+                co = _zl.compressobj(1, _zl.DEFLATED, 15, 8, _zl.Z_RLE)
+                return co.compress(raw) + co.flush()
+
+            def png_kernels(zstreams, npng, what):
+                desc = (_d.PngDesc * npng)()
+                blob, offs = bytearray(), []
+                for z in zstreams:
+                    while len(blob) % 16:
+                        blob.append(0)
+                    offs.append((len(blob), len(z)))
+                    blob += z
                 while len(blob) % 16:
                     blob.append(0)
-                offs.append((len(blob), len(z)))
-                blob += z
-            while len(blob) % 16:
-                blob.append(0)
-            for i in range(npng):
-                desc[i].zoff, desc[i].zlen = offs[i % 128]
-                desc[i].width, desc[i].height, desc[i].color_type = modeb.IMG, modeb.IMG, 2
-            d_z = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(dev)
-            d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
-            L = _d.load_library()
-            ss = int(L.cimbar_hip_png_scratch_bytes(modeb.IMG, modeb.IMG, 2))
-            d_scr = torch.empty(npng * ss, dtype=torch.uint8, device=dev)
-            d_rgb = torch.empty((npng, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
-            d_st = torch.zeros(npng, dtype=torch.int32, device=dev)
-            best = None
-            for _ in range(3):
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                L.cimbar_hip_png_decode_batch(dev.index, d_z.data_ptr(), d_z.numel(), d_desc.data_ptr(), npng, d_scr.data_ptr(), ss, d_rgb.data_ptr(),
-                                              modeb.FRAME_RGB_BYTES, d_st.data_ptr(), _ct.c_void_p(stream.cuda_stream))
-                torch.cuda.synchronize(dev)
-                dtk = time.perf_counter() - t0
-                best = dtk if best is None or dtk < best else best
-            fr128 = torch.from_numpy(host128).to(dev)
-            okk = bool((d_st == 0).all().item()) and all(bool((d_rgb[i] == fr128[i % 128]).all().item()) for i in range(0, npng, 61))
-            out["png_device_kernels"] = {"images": npng, "ms": round(best * 1e3, 2), "images_per_s": round(npng / best, 1), "pixels_ok": okk,
-                                         "avg_zlib_bytes": int(sum(l for _o, l in offs) / 128),
-                                         "note": "cimbar_hip_png_decode_batch on device-resident zlib streams of 1024x1024 frame PNGs (Pillow, compress_level 1): "
-                                                 "inflate (four streams per wavefront at this size) + un-filter"}
-            del d_scr, d_rgb, fr128
+                for i in range(npng):
+                    desc[i].zoff, desc[i].zlen = offs[i % len(offs)]
+                    desc[i].width, desc[i].height, desc[i].color_type = modeb.IMG, modeb.IMG, 2
+                d_z = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(dev)
+                d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
+                ss = int(L.cimbar_hip_png_scratch_bytes(modeb.IMG, modeb.IMG, 2))
+                d_scr = torch.empty(npng * ss, dtype=torch.uint8, device=dev)
+                d_rgb = torch.empty((npng, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+                d_st = torch.zeros(npng, dtype=torch.int32, device=dev)
+                best = None
+                for _ in range(3):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    L.cimbar_hip_png_decode_batch(dev.index, d_z.data_ptr(), d_z.numel(), d_desc.data_ptr(), npng, d_scr.data_ptr(), ss, d_rgb.data_ptr(),
+                                                  modeb.FRAME_RGB_BYTES, d_st.data_ptr(), _ct.c_void_p(stream.cuda_stream))
+                    torch.cuda.synchronize(dev)
+                    dtk = time.perf_counter() - t0
+                    best = dtk if best is None or dtk < best else best
+                fr128 = torch.from_numpy(host128).to(dev)
+                okk = bool((d_st == 0).all().item()) and all(bool((d_rgb[i] == fr128[i % len(offs)]).all().item()) for i in range(0, npng, 61))
+                del d_scr, d_rgb, fr128, d_z
+                torch.cuda.empty_cache()
+                return {"images": npng, "ms": round(best * 1e3, 2), "images_per_s": round(npng / best, 1), "pixels_ok": okk,
+                        "avg_zlib_bytes": int(sum(l for _o, l in offs) / len(offs)),
+                        "note": f"cimbar_hip_png_decode_batch on device-resident zlib streams of 1024x1024 frame PNGs ({what}): "
+                                "inflate (four streams per wavefront at this size) + un-filter"}
+
+            out["png_device_kernels"] = png_kernels([_d.png_split(open(paths[k], "rb").read())[5] for k in range(128)], 8192, "Pillow, compress_level 1")
+            out["png_device_kernels_cv_writer"] = png_kernels([cv_default_zlib(host128[k]) for k in range(32)], 8192,
+                                                              "cv::imwrite's defaults = the reference encoder's files: Sub filter, Z_RLE, level 1")
     except Exception as e:
         out["ingest"] = {"error": repr(e)}
     # ---- modes 67 ("Bm", Conf8x8_mini: 1024x720 frames, 12 x 429 bytes), 66 ("Bu", Conf8x8_micro: 736x637, 6 x 540) and 4 (legacy 4-colour:
