@@ -414,6 +414,37 @@ def extras(dec, dev, stream, n, outs, steps):
                         "note": f"cimbar_hip_png_decode_batch on device-resident zlib streams of 1024x1024 frame PNGs ({what}): "
                                 "inflate (four streams per wavefront at this size) + un-filter"}
 
+            # files -> chunks once more with the reference encoder's kind of file
+            def cv_default_png(img):
+                def chunk(t, d):
+                    return _st.pack(">I", len(d)) + t + d + _st.pack(">I", _zl.crc32(t + d) & 0xFFFFFFFF)
+                return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", _st.pack(">IIBBBBB", img.shape[1], img.shape[0], 8, 2, 0, 0, 0)) +
+                        chunk(b"IDAT", cv_default_zlib(img)) + chunk(b"IEND", b""))
+            try:
+                with tempfile.TemporaryDirectory() as td2:
+                    paths2 = []
+                    for k in range(128):
+                        pth = os.path.join(td2, f"c{k:03d}.png")
+                        with open(pth, "wb") as f:
+                            f.write(cv_default_png(host128[k]))
+                        paths2.append(pth)
+                    size2 = sum(os.path.getsize(x) for x in paths2) / len(paths2)
+                    mm2 = 16384
+                    paths2 = paths2 * (mm2 // 128)
+                    ing = ingest.Ingest(dec, threads=0, batch_frames=4096, ring=3, png_device=True, zbytes_per_frame=420000)
+                    ing.run_files(paths2[:256])
+                    t0 = time.perf_counter()
+                    total, chunks, masks = ing.run_files(paths2)
+                    dt = time.perf_counter() - t0
+                    ps = ing.png_stats()
+                    ing.close()
+                    ok2 = total == mm2 * 7500 and bool((torch.from_numpy(chunks[:128]) == payload.cpu()).all())
+                    out["ingest_png_device_cv_writer"] = {"files": mm2, "ms": round(dt * 1e3, 3), "frames_per_s": round(mm2 / dt, 1), "payload_ok": ok2,
+                                                          "avg_png_bytes": int(size2), "refused": ps["refused_by_host_walk"] + ps["refused_by_device"],
+                                                          "note": "the same path on PNGs as cv::imwrite writes them by default (Sub filter, Z_RLE, level 1: the "
+                                                                  "reference encoder's files) -- five times the deflate tokens of Pillow's"}
+            except Exception as e:
+                out["ingest_png_device_cv_writer"] = {"error": repr(e)}
             out["png_device_kernels"] = png_kernels([_d.png_split(open(paths[k], "rb").read())[5] for k in range(128)], 8192, "Pillow, compress_level 1")
             out["png_device_kernels_cv_writer"] = png_kernels([cv_default_zlib(host128[k]) for k in range(32)], 8192,
                                                               "cv::imwrite's defaults = the reference encoder's files: Sub filter, Z_RLE, level 1")
