@@ -130,6 +130,14 @@ def cases(frame=None, seed=7, big=True):
     # Z_BEST_SPEED, strategy Z_RLE): streams of short literal codes -- the inflate kernels' literal-burst path
     for nm, im in (("crop", crop), ("noise", noise), ("black", black), ("grad", grad)):
         out.append((f"{nm}_cvdefault", make_png(im, [1] * im.shape[0], level=1, strategy=zlib.Z_RLE), im))
+    # the Sub / None-only un-filter (rows are prefix sums): widths of 16 k pixels, one lane short of a wavefront (736 = mode Bu), two segments
+    # (1040, 2048), None and Sub rows mixed, a single row
+    for (hh, ww) in ((130, 256), (37, 736), (5, 1040), (3, 2048), (1, 16), (70, 1024)):
+        im = np.ascontiguousarray(np.tile(crop, (1 + hh // crop.shape[0], 1 + ww // crop.shape[1], 1))[:hh, :ww])
+        if ww == 736:
+            im = g.integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+        out.append((f"sub_{hh}x{ww}", make_png(im, [1] * hh, level=1, strategy=zlib.Z_RLE), im))
+        out.append((f"subnone_{hh}x{ww}", make_png(im, g.integers(0, 2, hh), level=1), im))
     out.append(("crop_sub_huff", make_png(crop, [1] * crop.shape[0], level=6, strategy=zlib.Z_HUFFMAN_ONLY), crop))   # literals only
     out.append(("crop_sub_fixed", make_png(crop, [1] * crop.shape[0], level=1, strategy=zlib.Z_FIXED), crop))         # 8- and 9-bit literals
     if big:
