@@ -154,7 +154,7 @@ def png_split(png):
     return w, h, ctype, depth, interlace, b"".join(z), pal
 
 
-def png_decode_batch_device(pngs, device=0):
+def png_decode_batch_device(pngs, device=0, variant=0):
     """PNG files (bytes) -> (list of (h, w, 3) uint8 arrays or None, status array): cimbar_hip_png_decode_batch on torch device buffers.
     Test / bench plumbing: packs the streams the way libcimbar_ingest.so's device mode does."""
     import torch
@@ -187,8 +187,11 @@ def png_decode_batch_device(pngs, device=0):
     d_scratch = torch.empty(n * sstride, dtype=torch.uint8, device=dev)
     d_rgb = torch.zeros(n * rstride, dtype=torch.uint8, device=dev)
     d_status = torch.full((n,), 12345, dtype=torch.int32, device=dev)
-    rc = lib.cimbar_hip_png_decode_batch(device, d_z.data_ptr(), d_z.numel(), d_desc.data_ptr(), n, d_scratch.data_ptr(), sstride, d_rgb.data_ptr(), rstride,
-                                         d_status.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    # variant: cimbar_hip_png_decode_batch_v's (0 = chosen by n, 1 = one stream per wavefront, 4 = "many in flight": the device chooses the kernel)
+    lib.cimbar_hip_png_decode_batch_v.restype = ctypes.c_int
+    rc = lib.cimbar_hip_png_decode_batch_v(device, ctypes.c_void_p(d_z.data_ptr()), ctypes.c_size_t(d_z.numel()), ctypes.c_void_p(d_desc.data_ptr()), n,
+                                           ctypes.c_void_p(d_scratch.data_ptr()), ctypes.c_size_t(sstride), ctypes.c_void_p(d_rgb.data_ptr()), ctypes.c_size_t(rstride),
+                                           ctypes.c_void_p(d_status.data_ptr()), int(variant), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise CimbarHipError(f"cimbar_hip_png_decode_batch: {rc}")
     torch.cuda.synchronize(dev)

@@ -14,15 +14,17 @@ pytestmark = pytest.mark.gpu
 
 # the inflate kernel's variants: one stream per wavefront with the whole deflate window in LDS | with an 8 KiB ring + far matches read back from
 # global memory; four streams per wavefront (sixteen lanes each) with a 2 KiB | 4 KiB ring
-VARIANTS = ["32768", "8192", "simt2048", "simt4096"]
+# "par...": the one-stream kernel with the all-offsets turn (every lane decodes the token that would start at its bit of the window)
+VARIANTS = ["32768", "8192", "simt2048", "simt4096", "par8192", "par32768"]
 
 
 def select(monkeypatch, variant):
+    monkeypatch.setenv("CIMBAR_HIP_PNG_PAR", "1" if variant.startswith("par") else "0")
     if variant.startswith("simt"):
         monkeypatch.setenv("CIMBAR_HIP_PNG_SIMT", variant[4:])
     else:
         monkeypatch.setenv("CIMBAR_HIP_PNG_SIMT", "0")
-        monkeypatch.setenv("CIMBAR_HIP_PNG_RING", variant)
+        monkeypatch.setenv("CIMBAR_HIP_PNG_RING", variant[3:] if variant.startswith("par") else variant)
 
 
 @pytest.mark.parametrize("ring", VARIANTS)
@@ -148,3 +150,23 @@ def test_ingest_device_png_mode_equals_host_mode(tmp_path, synth, hip_decoder, m
     assert (cd[good] == payload.reshape(12, -1)).all()
     assert stats["files"] == len(mixed) and stats["refused_by_host_walk"] == 3 and stats["refused_by_device"] == 1
     assert 0 < stats["bytes_to_device"] < 12 * 1024 * 1024 * 3 // 2
+
+
+@pytest.mark.parametrize("first", ["pillow_l1", "crop_cvdefault", "black_f0"])
+def test_device_chooses_the_inflate_kernel_for_large_launches(synth, hip_decoder, monkeypatch, first):
+    """variant 4 ("many images in flight") without overrides: a one-wavefront launch classifies the first image's first block, both inflate kernels
+    are enqueued and the one not named returns at once. Whatever it picks -- Pillow's long matches first: four streams per wavefront; a
+    cv::imwrite-style stream first: the all-offsets turn; a stream that begins with something else -- every image decodes."""
+    from libcimbar_amd import decoder
+    for k in ("CIMBAR_HIP_PNG_SIMT", "CIMBAR_HIP_PNG_RING", "CIMBAR_HIP_PNG_PAR"):
+        monkeypatch.delenv(k, raising=False)
+    _p, frames = clean_frames(synth, 1, seed=5151)
+    cs = png_cases.cases(frames[0], big=False)
+    lead = [c for c in cs if c[0] == first]
+    assert lead, first
+    cs = lead + [c for c in cs if c[0] != first]
+    got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs], variant=4)
+    bad = [(name, int(st)) for (name, _png, _w), st in zip(cs, status) if st != 0]
+    assert not bad, bad
+    for (name, png, want), img in zip(cs, got):
+        assert img.shape == want.shape and (img == want).all(), name
