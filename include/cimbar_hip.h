@@ -248,9 +248,11 @@ typedef struct cimbar_hip_png_desc {
 size_t cimbar_hip_png_scratch_bytes(unsigned width, unsigned height, unsigned color_type);
 int cimbar_hip_png_decode_batch(int device, const uint8_t* d_zbuf, size_t zbuf_bytes, const cimbar_hip_png_desc* d_desc, int n, uint8_t* d_scratch,
                                 size_t scratch_stride, uint8_t* d_rgb, size_t rgb_stride, int32_t* d_status, void* hip_stream);
-/* the same with the inflate kernel chosen by the caller: 0 = by n (what the call above does), 1 = one stream per wavefront (shortest time for a
- * lone launch of up to a few thousand images), 4 = four streams per wavefront (highest throughput once 8192+ images are in flight, whether in
- * one launch or in several concurrent ones -- what the ingest library's device mode keeps going) */
+/* the same with a hint about the launch: 0 = decide by n (what the call above does), 1 = one stream per wavefront (shortest time for a lone
+ * launch of up to a few thousand images), 4 = "8192+ images are in flight", whether in one launch or in several concurrent ones (what the
+ * ingest library's device mode keeps going). For 4 (and for 0 with n >= 8192) the DEVICE picks the inflate kernel: streams of long matches
+ * (frames as Pillow writes them) are fastest four to a wavefront, streams with short literal codes (cv::imwrite's defaults: the reference
+ * encoder's files) through the one-stream kernel's all-offsets turn; the first image's first block decides for the launch. */
 int cimbar_hip_png_decode_batch_v(int device, const uint8_t* d_zbuf, size_t zbuf_bytes, const cimbar_hip_png_desc* d_desc, int n, uint8_t* d_scratch,
                                   size_t scratch_stride, uint8_t* d_rgb, size_t rgb_stride, int32_t* d_status, int variant, void* hip_stream);
 

@@ -197,3 +197,23 @@ def fuzz_cases(n, seed):
                        mem=int(g.integers(1, 10)), ctype=ctype, palette=pal, idat_split=int(g.choice([0, 0, 100, 8192])))
         out.append((f"fuzz{seed}_{i}_{h}x{w}x{bpp}_k{kind}" + ("_pal" if ctype == 3 else ""), png, to_rgb(im, ctype, pal)))
     return out
+
+
+def ring_stress_cases(seed=11):
+    """images whose deflate streams are full of matches from just inside to just outside the kernels' LDS rings (8 KiB ring: distances around
+    8192 - 2048 and 8192 - 320; whole-window kernels: around 32768 - 2048 .. 32768), with a few literals between them: rows that repeat k rows
+    up with sparse random changes, so that zlib finds its matches at k * (3 w + 1) bytes. What the all-offsets turn must get right: a turn's
+    literals are stored before its matches are copied, so a match from far back must not find them where its source was."""
+    g = np.random.default_rng(seed)
+    out = []
+    for (w, k, h) in ((683, 3, 40), (682, 3, 40), (700, 3, 36), (655, 4, 44), (683, 4, 44), (640, 4, 40), (2047, 1, 30), (1366, 2, 30), (1300, 2, 30),
+                      (2040, 5, 60), (2047, 5, 60), (2048, 5, 60), (1800, 6, 60), (1820, 6, 60), (1707, 6, 60)):
+        for changes in (0.002, 0.02):
+            img = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            for r in range(k, h):
+                img[r] = img[r - k]
+                m = g.random((w, 3)) < changes
+                img[r][m] = g.integers(0, 256, int(m.sum()), dtype=np.uint8)
+            for lvl in (1, 9):
+                out.append((f"ring_w{w}_k{k}_c{changes}_l{lvl}", make_png(img, [0] * h, level=lvl), img))
+    return out

@@ -170,3 +170,15 @@ def test_device_chooses_the_inflate_kernel_for_large_launches(synth, hip_decoder
     assert not bad, bad
     for (name, png, want), img in zip(cs, got):
         assert img.shape == want.shape and (img == want).all(), name
+
+
+@pytest.mark.parametrize("ring", VARIANTS)
+def test_device_png_matches_around_the_ring_boundaries(hip_decoder, monkeypatch, ring):
+    from libcimbar_amd import decoder
+    select(monkeypatch, ring)
+    cs = png_cases.ring_stress_cases()
+    got, status = decoder.png_decode_batch_device([png for _n, png, _w in cs])
+    bad = [(name, int(st)) for (name, _p, _w), st in zip(cs, status) if st != 0]
+    assert not bad, bad[:10]
+    wrong = [name for (name, _p, want), img in zip(cs, got) if img.shape != want.shape or not (img == want).all()]
+    assert not wrong, wrong[:10]
