@@ -348,7 +348,7 @@ def extras(dec, dev, stream, n, outs, steps):
                 paths.append(pth)
             mm = 32768
             paths = paths * (mm // 128)
-            ing = ingest.Ingest(dec, threads=0, batch_frames=4096, ring=3, png_device=True, zbytes_per_frame=360000)
+            ing = ingest.Ingest(dec, threads=0, batch_frames=2048, ring=3, png_device=True, zbytes_per_frame=400000)
             ing.run_files(paths[:256])
             t0 = time.perf_counter()
             total, chunks, masks = ing.run_files(paths)
@@ -360,7 +360,7 @@ def extras(dec, dev, stream, n, outs, steps):
                                         "host_cpu_s": round(tm["host_fill_s"], 3), "device_wait_s": round(tm["device_wait_s"], 4),
                                         "pcie_bytes_per_frame": int(ps["bytes_to_device"] / mm), "refused": ps["refused_by_host_walk"] + ps["refused_by_device"],
                                         "note": "PNG files -> cimbar_ingest_run_files in device PNG mode: compressed bytes over PCIe, k_png_inflate + "
-                                                "k_png_unfilter + decode on the device (up to 3 batches of 4096 in flight: the four-streams-per-wavefront inflate)"}
+                                                "k_png_unfilter + decode on the device (up to 3 batches of 2048 in flight: the one-stream inflate with the all-offsets turn; measured against 3 x 4096 with the device-chosen kernel: 26.7 vs 24.7 k frames/s)"}
             # the two PNG kernels alone on device-resident streams, for the two kinds of PNG a frame comes as: Pillow's writer (adaptive
             # filters, deflate level 1: long matches) and cv::imwrite's defaults, i.e. the reference encoder's own files (Sub filter on every
             # row, Z_RLE, level 1: mostly 2-bit literals -- five times the tokens)
@@ -431,7 +431,7 @@ def extras(dec, dev, stream, n, outs, steps):
                     size2 = sum(os.path.getsize(x) for x in paths2) / len(paths2)
                     mm2 = 16384
                     paths2 = paths2 * (mm2 // 128)
-                    ing = ingest.Ingest(dec, threads=0, batch_frames=4096, ring=3, png_device=True, zbytes_per_frame=420000)
+                    ing = ingest.Ingest(dec, threads=0, batch_frames=2048, ring=3, png_device=True, zbytes_per_frame=460000)
                     ing.run_files(paths2[:256])
                     t0 = time.perf_counter()
                     total, chunks, masks = ing.run_files(paths2)
