@@ -75,3 +75,34 @@ def test_model_fuzz(model, chunk, ring):
             continue                     # a palette image: the model stops at the indices
         rgb = got if got.shape[2] == 3 else got[..., :3] if got.shape[2] == 4 else np.repeat(got, 3, axis=2)
         assert (rgb == want).all(), name
+
+
+@pytest.mark.parametrize("ring", [8192, 32768])
+def test_model_all_offsets_turn(model, synth, ring):
+    """k_png_inflate<RING, true>'s turn (every lane decodes the token that would start at its bit of the window; literals stored ahead of the
+    turn's matches; short runs filled by their own lanes) on every case, a fuzz batch and the streams built around the ring limits -- the model
+    returns E_MODEL if a match's source could have been overwritten by something the turn stored ahead of it, or was not flushed yet."""
+    from tests.frames import clean_frames
+    model.png_model_chunk(64)
+    model.png_model_ring(ring)
+    model.png_model_par(1)
+    try:
+        _p, frames = clean_frames(synth, 1, seed=5151)
+        batch = png_cases.cases(frames[0], big=True) + png_cases.fuzz_cases(200, seed=ring) + png_cases.ring_stress_cases()
+        for name, png, want in batch:
+            rc, got = decode(model, png)
+            assert rc == 0, (name, rc)
+            if name == "palette" or name.endswith("_pal"):
+                continue
+            rgb = got if got.shape[2] == 3 else got[..., :3] if got.shape[2] == 4 else np.repeat(got, 3, axis=2)
+            assert (rgb == want).all(), name
+            if name in ("frame_cvdefault", "pillow_frame_l1"):
+                st = (ctypes.c_ulonglong * 8)()
+                model.png_model_stats(st)
+                # (nearly every token goes through the all-offsets turn, several per turn)
+                assert st[7] > 0 and (st[0] + st[1]) / st[7] > 2.5, (name, list(st))
+        for name, png in png_cases.corrupt_cases():
+            rc, _ = decode(model, png)
+            assert rc != 0, name
+    finally:
+        model.png_model_par(0)

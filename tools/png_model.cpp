@@ -162,7 +162,7 @@ const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129
 const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 const uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-unsigned long long g_stats[8];   // literals, matches, match bytes, blocks, stored bytes, overlapped matches, dynamic blocks
+unsigned long long g_stats[8];   // literals, matches, match bytes, blocks, stored bytes, overlapped matches, dynamic blocks, all-offsets turns
 
 struct Out {
 	uint8_t win[WIN];
@@ -196,6 +196,126 @@ inline uint32_t modsmall(uint32_t j, uint32_t d, float rcp)
 	if (r < 0) r += (int)d;
 	if (r >= (int)d) r -= (int)d;
 	return (uint32_t)r;
+}
+
+// ---- the all-offsets turn of k_png_inflate<RING, true> (csrc/png.hip.inc, par_build and the MODE == 2 turn): every lane o decodes the token that
+// would start at bit o of the window (9-bit tables: a code of more than 9 bits is "not decodable here"), the chain from offset 0 picks the real
+// ones, the turn's literals are stored at once, short runs whose byte is final are filled by their own lanes, the other matches copied in
+// order. Besides the bytes this checks what the kernel relies on: that no source byte of a match has been overwritten by something the turn
+// stored AHEAD of it (the ring holds RING bytes), and that a far match's source has been flushed. Returns 0 (turn done), -1 (the token at bp
+// is for the one-token path) or an error code.
+int PARMODE = 0;
+
+bool canon9(const Canon& c, uint32_t bits9, int* sym, int* len)
+{
+	uint32_t r = 0;
+	for (int i = 0; i < 9; ++i) r |= ((bits9 >> i) & 1u) << (8 - i);
+	for (int L = 9; L >= 1; --L) {
+		const uint32_t codeL = r >> (9 - L);
+		if (codeL - c.first[L] < c.count[L]) { *sym = c.sorted[(int32_t)codeL + c.base[L]]; *len = L; return true; }
+	}
+	return false;
+}
+
+int par_turn(BitReader& br, const Canon& ll, const Canon& dd, Out& o, float rcp_scale)
+{
+	br.ensure_window(br.bp);
+	const uint32_t kk = br.bp >> 5, sh0 = br.bp & 31u;
+	bool lit[64], mat[64];
+	uint32_t val[64], mlen[64], mdist[64], link[64], outlen[64];
+	for (int l = 0; l < 64; ++l) {
+		const uint32_t bit0 = sh0 + (uint32_t)l, w0 = kk + (bit0 >> 5), sh = bit0 & 31u;
+		const uint32_t d0 = br.lane_of(w0, 64), d1 = br.lane_of(w0 + 1, 64), d2 = br.lane_of(w0 + 2, 64);
+		const uint64_t B = (uint64_t)(uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) | ((uint64_t)(uint32_t)((((uint64_t)d2 << 32) | d1) >> sh) << 32);
+		lit[l] = mat[l] = false; val[l] = mlen[l] = mdist[l] = 0; outlen[l] = 0;
+		uint32_t bits = 0;
+		int sym, L1;
+		if (canon9(ll, (uint32_t)B & 511u, &sym, &L1)) {
+			if (sym < 256) { lit[l] = true; val[l] = (uint32_t)sym; bits = (uint32_t)L1; outlen[l] = 1; }
+			else if (sym >= 257 && sym <= 285) {
+				const uint32_t x1 = LEXT[sym - 257];
+				const uint32_t len = LBASE[sym - 257] + ((uint32_t)(B >> L1) & ((1u << x1) - 1u));
+				const uint64_t B2 = B >> ((uint32_t)L1 + x1);
+				int ds, L2;
+				if (canon9(dd, (uint32_t)B2 & 511u, &ds, &L2) && ds <= 29) {
+					const uint32_t x2 = DEXT[ds];
+					mat[l] = true; mlen[l] = len; outlen[l] = len;
+					mdist[l] = DBASE[ds] + ((uint32_t)(B2 >> L2) & ((1u << x2) - 1u));
+					bits = (uint32_t)L1 + x1 + (uint32_t)L2 + x2;
+				}
+			}
+		}
+		link[l] = (lit[l] || mat[l]) ? (uint32_t)l + bits : 128u;
+	}
+	if (g_chunk_fault) return E_MODEL;
+	bool vis[64] = {false};
+	uint32_t off = 0, t = 0;
+	for (;;) {
+		t = link[off];
+		if (t >= 64u) break;
+		vis[off] = true;
+		off = t;
+	}
+	if (!(t & 128u)) { vis[off] = true; off = t; }
+	bool any = false;
+	for (int l = 0; l < 64; ++l) any = any || vis[l];
+	if (!any) return -1;
+	uint32_t incl[64], acc = 0;
+	for (int l = 0; l < 64; ++l) { acc += vis[l] ? outlen[l] : 0u; incl[l] = acc; }
+	for (int l = 0; l < 64; ++l)
+		if (vis[l] && incl[l] > 1024u) {
+			if (l != 0) { for (int k = l; k < 64; ++k) vis[k] = false; off = (uint32_t)l; }
+			else return E_MODEL;
+			break;
+		}
+	int lastv = 0;
+	for (int l = 0; l < 64; ++l) if (vis[l]) lastv = l;
+	const uint32_t before = o.op, total = incl[lastv];
+	if (before + total > o.cap) return E_OUTSIZE;
+	for (int l = 0; l < 64; ++l) if (vis[l] && mat[l] && mdist[l] > before + (incl[l] - outlen[l])) return E_DIST;
+	if (RING >= 32768)
+		for (int l = 0; l < 64; ++l) if (vis[l] && mat[l] && mdist[l] > (uint32_t)RING - 2048u) return -1;     // token by token
+	const uint32_t nearlim = (uint32_t)RING - 2048u, turn_end = before + total;
+	for (int l = 0; l < 64; ++l) if (vis[l] && lit[l]) { o.win[(before + incl[l] - 1u) & WMASK] = (uint8_t)val[l]; g_stats[0]++; }
+	// short runs whose byte is final: all lanes read, then all write
+	bool own[64];
+	uint8_t fill[64];
+	int prev = -1;
+	for (int l = 0; l < 64; ++l) {
+		own[l] = vis[l] && mat[l] && mdist[l] == 1u && mlen[l] <= 32u && (prev < 0 || lit[prev]);
+		if (own[l]) fill[l] = o.win[(before + incl[l] - outlen[l] - 1u) & WMASK];
+		if (vis[l]) prev = l;
+	}
+	for (int l = 0; l < 64; ++l)
+		if (own[l]) { for (uint32_t j = 0; j < mlen[l]; ++j) o.win[(before + incl[l] - outlen[l] + j) & WMASK] = fill[l]; g_stats[1]++; g_stats[2] += mlen[l]; }
+	for (int l = 0; l < 64; ++l) {
+		if (!(vis[l] && mat[l]) || own[l]) continue;
+		const uint32_t at = before + incl[l] - outlen[l], len = mlen[l], dist = mdist[l], src0 = at - dist;
+		g_stats[1]++; g_stats[2] += len; if (dist < len) g_stats[5]++;
+		if (dist == 1u) {
+			const uint8_t b = o.win[src0 & WMASK];
+			for (uint32_t j = 0; j < len; ++j) o.win[(at + j) & WMASK] = b;
+		} else if (dist >= len && RING < 32768 && dist > nearlim) {
+			if (src0 + len > o.flushed) return E_MODEL;                          // a far source that has not been flushed
+			for (uint32_t j = 0; j < len; ++j) o.win[(at + j) & WMASK] = o.glob[src0 + j];
+		} else {
+			// in the ring: nothing this turn stored ahead (up to turn_end) may have landed on a source byte
+			if (turn_end - src0 > (uint32_t)RING) return E_MODEL;
+			const float rcp = rcp_scale / (float)dist;
+			for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+				uint8_t tmp[64];
+				const uint32_t m = len - c0 < 64 ? len - c0 : 64;
+				for (uint32_t q = 0; q < m; ++q) { const uint32_t j = c0 + q, r = dist >= len ? j : modsmall(j, dist, rcp); tmp[q] = o.win[(src0 + r) & WMASK]; }
+				for (uint32_t q = 0; q < m; ++q) o.win[(at + c0 + q) & WMASK] = tmp[q];
+			}
+		}
+	}
+	br.bp += off;
+	if ((br.bp >> 5) > br.nwords + 2) br.overrun = true;
+	o.op = before + total;
+	o.after(before);
+	g_stats[7]++;                 // turns taken by this path
+	return 0;
 }
 
 int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect, float rcp_scale)
@@ -281,6 +401,11 @@ int inflate_model(const uint8_t* zs, size_t zlen, uint8_t* out, uint32_t expect,
 			}
 			br.begin_symbols();
 			for (;;) {
+				if (PARMODE && CHUNK == 64) {
+					const int pr = par_turn(br, ll, dd, o, rcp_scale);
+					if (pr == 0) continue;
+					if (pr > 0) return pr;
+				}
 				br.token();
 				int sym;
 				int rc = canon_decode(ll, br, &sym);
@@ -508,6 +633,7 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 
 // PNG (8-bit gray / RGB / RGBA / palette, non-interlaced) -> un-filtered samples (h*w*bpp); returns 0 or a negative code; *pw,*ph,*pbpp set
 extern "C" void png_model_chunk(int chunk) { CHUNK = chunk; }
+extern "C" void png_model_par(int on) { PARMODE = on; }
 
 extern "C" void png_model_ring(int ring) { RING = ring; WMASK = ring - 1; FLUSH = ring >= 32768 ? 4096 : ring / 2; }
 
