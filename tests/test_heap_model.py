@@ -1,5 +1,5 @@
 """tools/heap_model.cpp -- the CPU model of the exact flood replay's lane-parallel heap operations (csrc/k2b_flood.hip.inc: WaveHeap::push,
-WaveHeap::pop with five heap levels per LDS round trip, WaveHeap6::pop6 with six, and k_flood3's rule for which entry is on top after a
+WaveHeap::pop with five heap levels per LDS round trip, WaveHeap7::pop7 with six, WaveHeap7::push4, and k_flood3's rule for which entry is on top after a
 step's pushes) against libstdc++'s own std::push_heap / std::pop_heap, which is what the reference's std::priority_queue runs
 (FloodDecodePositions.h:18-28,48). The kernels restate the model; tests/test_gpu_flood.py checks them against the oracle on the device."""
 import ctypes
@@ -29,7 +29,7 @@ CASES = [(1, 120000, 3, 60, 0), (2, 120000, 12, 30, 0), (3, 80000, 1, 80, 0), (4
          (13, 60000, 1, 0, 64), (14, 60000, 64, 0, 500), (15, 200000, 7, 0, 32760), (16, 100000, 3, 0, 16380)]
 
 
-# 5: WaveHeap::pop, 6: pop6, 7: pop7 (six levels, one write per path node), 8: pop7 + push4 (a burst's pushes four at a time, one gather and
+# 5: WaveHeap::pop, 6: the model's first six-level pop (the kernels' pop7 replaced it; kept as a second witness), 7: pop7 (six levels, one write per path node), 8: pop7 + push4 (a burst's pushes four at a time, one gather and
 # one scatter; seed 15 hovers where push4 hands over to the one-by-one push because an entry could have more than 14 ancestors)
 @pytest.mark.parametrize("levels", [5, 6, 7, 8])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"seed{c[0]}-prio{c[2]}-hover{c[4]}")

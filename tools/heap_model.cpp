@@ -1,5 +1,5 @@
 // heap_model.cpp -- CPU model of the lane-parallel heap operations of the exact flood replay (csrc/k2b_flood.hip.inc: WaveHeap::push,
-// WaveHeap::pop with five levels per round, WaveHeap6::pop6 with six) and of k_flood3's rule for the entry that is on top after a step's
+// WaveHeap::pop with five levels per round, WaveHeap7::pop7 with six, WaveHeap7::push4) and of k_flood3's rule for the entry that is on top after a step's
 // pushes, run against libstdc++'s own std::push_heap / std::pop_heap -- the thing FloodDecodePositions' std::priority_queue is made of
 // (FloodDecodePositions.h:18-28,48). Sixty-four "lanes" are arrays here; ballots are bit masks. Development aid (what is left to find on the
 // GPU is plumbing, not arithmetic); not part of the product and not an oracle for the decode path. Built and driven by tests/test_heap_model.py.
@@ -101,7 +101,7 @@ struct WaveHeapModel {
 		n += k;
 	}
 
-	// WaveHeap6::pop7 (the default since round 3): six levels per round like pop6, restated so that every node on the hole's path writes ONE slot
+	// WaveHeap7::pop7 (the default since round 3): six levels per round, restated so that every node on the hole's path writes ONE slot
 	// -- its own: H'[c_k] = H[c_{k+1}] for k < j (the value of the child the path goes to, which the lane has fetched anyway), H'[c_j] = value --
 	// and so that the node with a left child only (stl_heap.h __adjust_heap's `(len & 1) == 0 && secondChild == (len - 2) / 2` case) is just a
 	// node that "prefers" its only child: no tail case, no parent writes across blocks, the root (the hole) is an ordinary path node.
@@ -158,7 +158,7 @@ struct WaveHeapModel {
 		return j == 0 ? value : rootchild;
 	}
 
-	// LV = levels per round: 5 = WaveHeap::pop, 6 = WaveHeap6::pop6. Returns what the kernel reports as the root afterwards (0 if empty;
+	// LV = levels per round: 5 = WaveHeap::pop, 6 = a first six-level pop (no longer in the kernels: pop7 below replaced it). Returns what the kernel reports as the root afterwards (0 if empty;
 	// 0xFFFFFFFF if two of its scattered writes disagree about one slot).
 	uint32_t pop(int LV)
 	{
