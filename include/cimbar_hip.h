@@ -198,6 +198,37 @@ int64_t cimbar_hip_scan_extract_decode_batch(cimbar_hip_ctx* ctx, const uint8_t*
                                              int preprocess, int color_correction, uint8_t* chunks, uint32_t* masks, int* status, int out_mem,
                                              void* hip_stream);
 
+/* ---- the capture's pixel format: the `format` argument of the reference's own C ABI for this step ----------------------------------------
+ *     int cimbard_scan_extract_decode(const unsigned char* imgdata, unsigned imgw, unsigned imgh, int format, unsigned char* bufspace, unsigned bufsize)
+ *                                          src/lib/cimbar_js/cimbar_recv_js.h:17; get_rgb, cimbar_recv_js.cpp:94-120; `format <= 0` is 3, :150-151
+ * whose only camera caller hands over VideoFrames as they come: NV12 (12), I420 (420) or RGBA (4) (web/recv-worker.js:38-47, web/recv.js:110,362-371).
+ * The four entry points above with that argument in the reference's position (after the height). `img` = n captures of
+ * cimbar_hip_capture_bytes(width, height, format) bytes each, back to back:
+ *   3 (and <= 0, and any value the reference's `default:` lets through)  RGB8, width * height * 3
+ *   4    RGBA8, width * height * 4; the alpha byte is dropped (cv::COLOR_RGBA2RGB)
+ *   12   NV12: width * height luma bytes, then height / 2 rows of width bytes (U, V, U, V ...)        (cv::COLOR_YUV2RGB_NV12)
+ *   420  three planes: width * height luma, then two (width / 2) x (height / 2) chroma planes, read the way the reference's conversion code
+ *        cv::COLOR_YUV420p2RGB reads them -- OpenCV defines it as COLOR_YUV2RGB_YV12: the FIRST chroma plane is V. (An I420 VideoFrame has U
+ *        first; upstream decodes such captures with red and blue exchanged and leaves it to the header-derived colour correction. Kept.)
+ * YUV -> RGB is OpenCV's fixed-point BT.601, gray / blur / warp then see exactly the RGB image get_rgb would have built -- but no
+ * such image is ever written: the scan and warp kernels convert as they load, so a 1080p NV12 capture costs 3.1 MB of PCIe and HBM reads
+ * instead of 6.2. 12 and 420 need an even width and height (cv::cvtColor asserts it; upstream throws): CIMBAR_HIP_EDIM, and
+ * cimbar_hip_capture_bytes returns 0. Everything else as for the entry point without the suffix (which is format 3).
+ * cimbard_scan_extract_decode(img, w, h, format, buf, size) is then
+ *   cimbar_hip_scan_extract_decode_batch_fmt(ctx, img, w, h, format, 1, CIMBAR_HIP_MEM_HOST, 1, 2, chunks, &mask, &status, CIMBAR_HIP_MEM_HOST, NULL)
+ * (upstream always sharpens on this path: `bool shouldPreprocess = true`, cimbar_recv_js.cpp:166) with status 0 -> return -3 and the chunks
+ * whose mask bit is set packed front to back (escrow_buffer_writer); INTEGRATION.md has the wrapper. */
+size_t cimbar_hip_capture_bytes(unsigned width, unsigned height, int format);
+int cimbar_hip_scan_preprocess_fmt(cimbar_hip_ctx* ctx, const uint8_t* img, unsigned width, unsigned height, int format, int n, int img_mem,
+                                   uint8_t* binary, int* thresholds, int out_mem, void* hip_stream);
+int cimbar_hip_deskew_batch_fmt(cimbar_hip_ctx* ctx, const uint8_t* img, unsigned width, unsigned height, int format, int n, int img_mem,
+                                const float* corners, uint8_t* frames, int out_mem, void* hip_stream);
+int cimbar_hip_extract_batch_fmt(cimbar_hip_ctx* ctx, const uint8_t* img, unsigned width, unsigned height, int format, int n, int img_mem,
+                                 uint8_t* frames, int* status, float* corners, int out_mem, void* hip_stream);
+int64_t cimbar_hip_scan_extract_decode_batch_fmt(cimbar_hip_ctx* ctx, const uint8_t* img, unsigned width, unsigned height, int format, int n,
+                                                 int img_mem, int preprocess, int color_correction, uint8_t* chunks, uint32_t* masks, int* status,
+                                                 int out_mem, void* hip_stream);
+
 /* ---- multi-GPU: the one exchange step ------------------------------------------------------------------------------------
  * Frames are independent, so each GPU decodes its own slab with its own context; afterwards every rank's n x (7500 chunk bytes + 1 mask
  * word) are gathered on `root` in rank order (== frame order for contiguous slabs), where the host feeds the single fountain_decoder_sink

@@ -64,6 +64,11 @@ int cimbar_ingest_create_ex(cimbar_hip_ctx* ctx, int threads, int batch_frames, 
 int cimbar_ingest_png_stats(const cimbar_ingest* ing, int64_t out4[4]);
 /* device PNG mode, last cimbar_ingest_run_files: files decoded on the host instead (JPEG, PNGs the kernels do not take) */
 int64_t cimbar_ingest_host_decoded(const cimbar_ingest* ing);
+/* device PNG mode, last cimbar_ingest_run_files: readable, right-sized files that needed the host decoder AFTER their batch's 32 fallback frames
+ * were taken and were therefore dropped (cv::imread would have decoded them). They are also part of png_stats [1], but unlike an unreadable
+ * file they are a capacity limit of this library: a caller that feeds directories of JPEGs / 16-bit PNGs should use a host-mode ingest, and
+ * one that sees a non-zero count here has lost frames. Not handled at all: EXIF orientation (cv::imread rotates by it; csrc/jpeg.inc does not). */
+int64_t cimbar_ingest_fallback_overflow(const cimbar_ingest* ing);
 void cimbar_ingest_destroy(cimbar_ingest* ing);
 const char* cimbar_ingest_last_error(const cimbar_ingest* ing);
 

@@ -247,6 +247,7 @@ struct cimbar_ingest {
 	hipStream_t copy_stream = nullptr, out_stream = nullptr;
 	double t_wall = 0, t_host = 0, t_wait = 0;
 	int64_t png_files = 0, png_refused_host = 0, png_refused_device = 0, png_bytes = 0, host_decoded = 0;   // device PNG mode, last run
+	std::atomic<int64_t> fb_overflow{0};   // ... files that needed a host-decoded fallback frame when the batch's FB of them were taken (dropped; counted apart from unreadable files)
 };
 
 namespace {
@@ -277,6 +278,7 @@ int64_t run_pipeline(cimbar_ingest* ing, int n, int pre, int cc, cimbar_ingest_s
 	std::unique_ptr<std::atomic<size_t>[]> zcur(new std::atomic<size_t>[(size_t)nbatch]);
 	for (int k = 0; k < nbatch; ++k) zcur[(size_t)k].store(0);
 	ing->png_files = ing->png_refused_host = ing->png_refused_device = ing->png_bytes = ing->host_decoded = 0;
+	ing->fb_overflow = 0;
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<int> filled((size_t)nbatch, 0);      // frames of batch k staged so far
@@ -444,6 +446,7 @@ int cimbar_image_decode(const uint8_t* file, size_t len, uint8_t* rgb, size_t rg
 }
 
 int64_t cimbar_ingest_host_decoded(const cimbar_ingest* ing) { return ing ? ing->host_decoded : CIMBAR_HIP_EINVAL; }
+int64_t cimbar_ingest_fallback_overflow(const cimbar_ingest* ing) { return ing ? ing->fb_overflow.load() : CIMBAR_HIP_EINVAL; }
 
 int cimbar_ingest_create(cimbar_hip_ctx* ctx, int threads, int batch_frames, int ring, cimbar_ingest** out)
 {
@@ -575,7 +578,7 @@ int64_t cimbar_ingest_run_files(cimbar_ingest* ing, const char* const* paths, in
 				unsigned w = 0, h = 0;
 				if (image_decode(file.data(), file.size(), nullptr, 0, &w, &h, idat, raw) != 0 || w != ing->fw || h != ing->fh) return false;
 				const size_t idx = cursor.fetch_add(FB_ONE) >> 48;
-				if (idx >= (size_t)cimbar_ingest::FB) return false;      // more such files in one batch than it has room for: skipped
+				if (idx >= (size_t)cimbar_ingest::FB) { ing->fb_overflow.fetch_add(1); return false; }   // more such files in one batch than it has room for: dropped, and counted as exactly that
 				if (image_decode(file.data(), file.size(), sl.h_fb + idx * ing->frame, ing->frame, &w, &h, idat, raw) != 0) return false;
 				sl.fb_index[(size_t)j] = (int)idx;
 				return true;

@@ -30,6 +30,8 @@ EXPORTS = (
     "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
     "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
     "cimbar_hip_ctx_bufsize", "cimbar_hip_set_ccm",
+    "cimbar_hip_capture_bytes", "cimbar_hip_scan_preprocess_fmt", "cimbar_hip_deskew_batch_fmt", "cimbar_hip_extract_batch_fmt",
+    "cimbar_hip_scan_extract_decode_batch_fmt",
 )
 PNG_EHEADER, PNG_ESTREAM, PNG_ECODES, PNG_ESIZE, PNG_ECHECK = -30, -31, -32, -33, -34
 
@@ -90,6 +92,16 @@ def load_library(path=None):
     lib.cimbar_hip_extract_batch.restype = i32
     lib.cimbar_hip_scan_extract_decode_batch.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     lib.cimbar_hip_scan_extract_decode_batch.restype = i64
+    lib.cimbar_hip_capture_bytes.argtypes = [u32, u32, i32]
+    lib.cimbar_hip_capture_bytes.restype = sz
+    lib.cimbar_hip_scan_preprocess_fmt.argtypes = [vp, vp, u32, u32, i32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_scan_preprocess_fmt.restype = i32
+    lib.cimbar_hip_deskew_batch_fmt.argtypes = [vp, vp, u32, u32, i32, i32, i32, vp, vp, i32, vp]
+    lib.cimbar_hip_deskew_batch_fmt.restype = i32
+    lib.cimbar_hip_extract_batch_fmt.argtypes = [vp, vp, u32, u32, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.cimbar_hip_extract_batch_fmt.restype = i32
+    lib.cimbar_hip_scan_extract_decode_batch_fmt.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.cimbar_hip_scan_extract_decode_batch_fmt.restype = i64
     lib.cimbar_hip_comm_init_all.argtypes = [i32, vp, ctypes.POINTER(vp)]
     lib.cimbar_hip_comm_init_all.restype = i32
     lib.cimbar_hip_comm_unique_id.argtypes = [vp]
@@ -331,63 +343,72 @@ class HipDecoder:
         return int(self._lib.cimbar_hip_pipeline_depth(self._ctx))
 
     # ------------------------------------------------------------------ the stage in front: Scanner's image preparation, Deskewer
-    def scan_preprocess(self, captures):
-        """captures (n,h,w,3) uint8 numpy -> (binary (n,h,w) uint8 of 0/255, thresholds (n,) int32): Scanner::preprocess_image."""
+    def _captures(self, captures, size, fmt):
+        """RGB8 captures as an (n,h,w,3) array, or -- with size=(w,h) and the C ABI's `fmt` (3 RGB, 4 RGBA, 12 NV12, 420) -- n captures of
+        cimbar_hip_capture_bytes(w, h, fmt) bytes each as an (n, bytes) array. Returns (array, n, w, h, fmt)."""
         captures = np.ascontiguousarray(captures, dtype=np.uint8)
-        n, h, w = captures.shape[:3]
+        if size is None:
+            n, h, w = captures.shape[:3]
+            return captures, n, w, h, 3
+        w, h = size
+        per = int(self._lib.cimbar_hip_capture_bytes(w, h, int(fmt)))
+        if per == 0 or captures.size % per:
+            raise CimbarHipError(f"captures of {w}x{h} in format {fmt}: {captures.size} bytes is no multiple of {per}")
+        return captures, captures.size // per, w, h, int(fmt)
+
+    def scan_preprocess(self, captures, size=None, fmt=3):
+        """captures -> (binary (n,h,w) uint8 of 0/255, thresholds (n,) int32): Scanner::preprocess_image."""
+        captures, n, w, h, fmt = self._captures(captures, size, fmt)
         out = np.zeros((n, h, w), dtype=np.uint8)
         thr = np.zeros(n, dtype=np.int32)
-        self._check(self._lib.cimbar_hip_scan_preprocess(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, out.ctypes.data, thr.ctypes.data,
-                                                         MEM_HOST, None), "cimbar_hip_scan_preprocess")
+        self._check(self._lib.cimbar_hip_scan_preprocess_fmt(self._ctx, captures.ctypes.data, w, h, fmt, n, MEM_HOST, out.ctypes.data, thr.ctypes.data,
+                                                             MEM_HOST, None), "cimbar_hip_scan_preprocess_fmt")
         return out, thr
 
-    def deskew_batch(self, captures, corners):
-        """captures (n,h,w,3) uint8, corners (n,8) float32 (tl, tr, bl, br as x,y) -> frames (n,1024,1024,3): Deskewer::deskew."""
-        captures = np.ascontiguousarray(captures, dtype=np.uint8)
+    def deskew_batch(self, captures, corners, size=None, fmt=3):
+        """captures, corners (n,8) float32 (tl, tr, bl, br as x,y) -> frames (n,1024,1024,3): Deskewer::deskew."""
+        captures, n, w, h, fmt = self._captures(captures, size, fmt)
         corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
-        n, h, w = captures.shape[:3]
         out = np.zeros((n, *self.geo.FRAME_SHAPE), dtype=np.uint8)
-        self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, corners.ctypes.data, out.ctypes.data,
-                                                      MEM_HOST, None), "cimbar_hip_deskew_batch")
+        self._check(self._lib.cimbar_hip_deskew_batch_fmt(self._ctx, captures.ctypes.data, w, h, fmt, n, MEM_HOST, corners.ctypes.data, out.ctypes.data,
+                                                          MEM_HOST, None), "cimbar_hip_deskew_batch_fmt")
         return out
 
-    def deskew_batch_device(self, captures_ptr, w, h, n, corners, frames_ptr, stream=None):
+    def deskew_batch_device(self, captures_ptr, w, h, n, corners, frames_ptr, stream=None, fmt=3):
         """device captures -> device frames (what cimbar_hip_decode_batch takes next); corners stay a host array."""
         corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
-        self._check(self._lib.cimbar_hip_deskew_batch(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(n), MEM_DEVICE,
-                                                      corners.ctypes.data, ctypes.c_void_p(frames_ptr), MEM_DEVICE,
-                                                      ctypes.c_void_p(stream) if stream else None), "cimbar_hip_deskew_batch(device)")
+        self._check(self._lib.cimbar_hip_deskew_batch_fmt(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(fmt), int(n), MEM_DEVICE,
+                                                          corners.ctypes.data, ctypes.c_void_p(frames_ptr), MEM_DEVICE,
+                                                          ctypes.c_void_p(stream) if stream else None), "cimbar_hip_deskew_batch_fmt(device)")
 
-    def extract_batch(self, captures):
-        """Extractor::extract for captures (n,h,w,3) uint8 numpy -> (status (n,) int32, corners (n,8) float32, frames (n,1024,1024,3))"""
-        captures = np.ascontiguousarray(captures, dtype=np.uint8)
-        n, h, w = captures.shape[:3]
+    def extract_batch(self, captures, size=None, fmt=3):
+        """Extractor::extract for captures -> (status (n,) int32, corners (n,8) float32, frames (n,1024,1024,3))"""
+        captures, n, w, h, fmt = self._captures(captures, size, fmt)
         frames = np.zeros((n, *self.geo.FRAME_SHAPE), dtype=np.uint8)
         status = np.zeros(n, dtype=np.int32)
         corners = np.zeros((n, 8), dtype=np.float32)
-        self._check(self._lib.cimbar_hip_extract_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, frames.ctypes.data, status.ctypes.data,
-                                                       corners.ctypes.data, MEM_HOST, None), "cimbar_hip_extract_batch")
+        self._check(self._lib.cimbar_hip_extract_batch_fmt(self._ctx, captures.ctypes.data, w, h, fmt, n, MEM_HOST, frames.ctypes.data, status.ctypes.data,
+                                                           corners.ctypes.data, MEM_HOST, None), "cimbar_hip_extract_batch_fmt")
         return status, corners, frames
 
-    def scan_extract_decode_batch(self, captures, preprocess=-1, color_correction=2):
-        """cimbard_scan_extract_decode for captures (n,h,w,3) uint8 numpy -> (good_bytes, chunks (n,12,625), masks (n,), status (n,))"""
-        captures = np.ascontiguousarray(captures, dtype=np.uint8)
-        n, h, w = captures.shape[:3]
+    def scan_extract_decode_batch(self, captures, preprocess=-1, color_correction=2, size=None, fmt=3):
+        """cimbard_scan_extract_decode for n captures -> (good_bytes, chunks (n,12,625), masks (n,), status (n,))"""
+        captures, n, w, h, fmt = self._captures(captures, size, fmt)
         chunks = np.zeros((n, self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK), dtype=np.uint8)
         masks = np.zeros(n, dtype=np.uint32)
         status = np.zeros(n, dtype=np.int32)
-        rc = self._check(self._lib.cimbar_hip_scan_extract_decode_batch(self._ctx, captures.ctypes.data, w, h, n, MEM_HOST, int(preprocess),
-                                                                         int(color_correction), chunks.ctypes.data, masks.ctypes.data,
-                                                                         status.ctypes.data, MEM_HOST, None), "cimbar_hip_scan_extract_decode_batch")
+        rc = self._check(self._lib.cimbar_hip_scan_extract_decode_batch_fmt(self._ctx, captures.ctypes.data, w, h, fmt, n, MEM_HOST, int(preprocess),
+                                                                             int(color_correction), chunks.ctypes.data, masks.ctypes.data,
+                                                                             status.ctypes.data, MEM_HOST, None), "cimbar_hip_scan_extract_decode_batch_fmt")
         return int(rc), chunks, masks, status
 
-    def scan_extract_decode_device(self, captures_ptr, w, h, n, chunks_ptr, masks_ptr, status_ptr=None, preprocess=-1, color_correction=2, stream=None):
+    def scan_extract_decode_device(self, captures_ptr, w, h, n, chunks_ptr, masks_ptr, status_ptr=None, preprocess=-1, color_correction=2, stream=None, fmt=3):
         """device captures in, device chunks / masks / status out; asynchronous on `stream`"""
-        self._check(self._lib.cimbar_hip_scan_extract_decode_batch(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(n), MEM_DEVICE,
-                                                                    int(preprocess), int(color_correction), ctypes.c_void_p(chunks_ptr),
-                                                                    ctypes.c_void_p(masks_ptr), ctypes.c_void_p(status_ptr) if status_ptr else None,
-                                                                    MEM_DEVICE, ctypes.c_void_p(stream) if stream else None),
-                    "cimbar_hip_scan_extract_decode_batch(device)")
+        self._check(self._lib.cimbar_hip_scan_extract_decode_batch_fmt(self._ctx, ctypes.c_void_p(captures_ptr), int(w), int(h), int(fmt), int(n), MEM_DEVICE,
+                                                                        int(preprocess), int(color_correction), ctypes.c_void_p(chunks_ptr),
+                                                                        ctypes.c_void_p(masks_ptr), ctypes.c_void_p(status_ptr) if status_ptr else None,
+                                                                        MEM_DEVICE, ctypes.c_void_p(stream) if stream else None),
+                    "cimbar_hip_scan_extract_decode_batch_fmt(device)")
 
     # ------------------------------------------------------------------ the reference's operator surface
     def decode_fountain(self, img, ostream, should_preprocess=False, color_correction=2):

@@ -10,7 +10,7 @@ from . import decoder
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcimbar_ingest.so")
 EXPORTS = ("cimbar_png_decode", "cimbar_ingest_create", "cimbar_ingest_destroy", "cimbar_ingest_last_error", "cimbar_ingest_run_files",
-           "cimbar_ingest_run_raw", "cimbar_ingest_timings", "cimbar_ingest_create_ex", "cimbar_ingest_png_stats", "cimbar_jpeg_decode",
+           "cimbar_ingest_run_raw", "cimbar_ingest_timings", "cimbar_ingest_create_ex", "cimbar_ingest_png_stats", "cimbar_jpeg_decode", "cimbar_ingest_fallback_overflow",
            "cimbar_image_decode", "cimbar_ingest_host_decoded")
 PNG_HOST, PNG_DEVICE = 0, 1
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int)
@@ -157,6 +157,12 @@ class Ingest:
     def host_decoded(self):
         """device PNG mode, last run_files: files the host threads decoded instead (JPEG, PNGs the kernels do not take)"""
         return int(self._lib.cimbar_ingest_host_decoded(self._h))
+
+    def fallback_overflow(self):
+        """device PNG mode, last run_files: readable files dropped because their batch's 32 host-decoded fallback frames were taken"""
+        self._lib.cimbar_ingest_fallback_overflow.restype = ctypes.c_int64
+        self._lib.cimbar_ingest_fallback_overflow.argtypes = [ctypes.c_void_p]
+        return int(self._lib.cimbar_ingest_fallback_overflow(self._h))
 
     def timings(self):
         out = (ctypes.c_double * 3)()

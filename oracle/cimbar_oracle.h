@@ -14,6 +14,7 @@
  */
 #ifndef CIMBAR_ORACLE_H
 #define CIMBAR_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -151,6 +152,12 @@ int co_deskew(const uint8_t* rgb, int sw, int sh, const float* corners8, uint8_t
 int co_scan_anchors(const uint8_t* binary, int w, int h, int32_t* anchors16);
 /* Extractor::extract (Extractor.h:29-45): 0 failure / 1 success / 2 needs sharpen; corners8 = Corners::all(); out = deskewed 1024x1024 RGB8 */
 int co_extract(const uint8_t* rgb, int w, int h, uint8_t* out1024, float* corners8);
+
+/* get_rgb (cimbar_js/cimbar_recv_js.cpp:94-120): a capture in the C ABI's `format` (3 RGB, 4 RGBA, 12 NV12, 420 = COLOR_YUV420p2RGB) -> RGB8.
+ * co_capture_bytes: the bytes such a capture occupies (0: the format cannot hold that size). co_capture_to_rgb returns 0, or -1 for such a size. */
+size_t co_capture_bytes(int w, int h, int format);
+int co_capture_to_rgb(const uint8_t* img, int w, int h, int format, uint8_t* rgb);
+int co_extract_fmt(const uint8_t* img, int w, int h, int format, uint8_t* out1024, float* corners8);
 
 #ifdef __cplusplus
 }

@@ -531,3 +531,59 @@ int co_extract(const uint8_t* rgb, int w, int h, uint8_t* out1024, float* corner
 	}
 	return granular ? 1 : 2;
 }
+
+/* ---- the capture formats of the reference's C ABI: get_rgb (src/lib/cimbar_js/cimbar_recv_js.cpp:94-120) behind
+ * cimbard_scan_extract_decode(img, w, h, format, ...) (cimbar_recv_js.h:17; callers web/recv-worker.js:38-47). `format` as the reference
+ * reads it: 12 = NV12 -> cvtColor(COLOR_YUV2RGB_NV12); 420 -> cvtColor(COLOR_YUV420p2RGB), which OpenCV defines as COLOR_YUV2RGB_YV12 (the
+ * plane behind Y is read as V, the next one as U -- kept, not "fixed"); 4 = RGBA -> cvtColor(COLOR_RGBA2RGB); everything else (3, and any
+ * value get_rgb's `default:` lets through) = RGB8 as it is; `format <= 0` is 3 (:150-151).
+ * [assumed-OpenCV] color_yuv.simd.hpp, BT.601 in 20-bit fixed point: ITUR_BT_601_CY 1220542, CUB 2116026, CUG -409993, CVG -852492, CVR 1673527;
+ *   ruv = 2^19 + CVR (v - 128);  guv = 2^19 + CVG (v - 128) + CUG (u - 128);  buv = 2^19 + CUB (u - 128);  y' = max(0, y - 16) CY
+ *   R, G, B = saturate_cast<uchar>((y' + cuv) >> 20)
+ * One (u, v) pair per 2x2 block of pixels. The 4:2:0 layouts need an even width and an even height (OpenCV asserts that; the reference would
+ * throw): co_capture_bytes returns 0 for them and co_capture_to_rgb -1. */
+size_t co_capture_bytes(int w, int h, int format)
+{
+	if (w <= 0 || h <= 0) return 0;
+	if (format == 12 || format == 420) return (w % 2 || h % 2) ? 0 : (size_t)w * h * 3 / 2;
+	return (size_t)w * h * (format == 4 ? 4 : 3);
+}
+
+static uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+int co_capture_to_rgb(const uint8_t* img, int w, int h, int format, uint8_t* rgb)
+{
+	if (format <= 0) format = 3;
+	if (!co_capture_bytes(w, h, format)) return -1;
+	const size_t n = (size_t)w * h;
+	if (format == 12 || format == 420) {
+		const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SHIFT = 20;
+		const uint8_t* cplane = img + n;              /* NV12: h/2 rows of w bytes (u, v, u, v ...); 420: a w/2 x h/2 plane read as V, then one read as U */
+		const size_t csize = (size_t)(w / 2) * (h / 2);
+		for (int y = 0; y < h; ++y)
+			for (int x = 0; x < w; ++x) {
+				int u, v;
+				if (format == 12) { const uint8_t* p = cplane + (size_t)(y / 2) * w + (x / 2) * 2; u = p[0]; v = p[1]; }
+				else { const size_t ci = (size_t)(y / 2) * (w / 2) + x / 2; v = cplane[ci]; u = cplane[csize + ci]; }
+				const int uu = u - 128, vv = v - 128;
+				const int ruv = (1 << (SHIFT - 1)) + CVR * vv, guv = (1 << (SHIFT - 1)) + CVG * vv + CUG * uu, buv = (1 << (SHIFT - 1)) + CUB * uu;
+				const int yy = img[(size_t)y * w + x] - 16, yv = (yy < 0 ? 0 : yy) * CY;
+				uint8_t* o = rgb + ((size_t)y * w + x) * 3;
+				o[0] = sat_u8((yv + ruv) >> SHIFT); o[1] = sat_u8((yv + guv) >> SHIFT); o[2] = sat_u8((yv + buv) >> SHIFT);
+			}
+		return 0;
+	}
+	if (format == 4) { for (size_t i = 0; i < n; ++i) { rgb[3 * i] = img[4 * i]; rgb[3 * i + 1] = img[4 * i + 1]; rgb[3 * i + 2] = img[4 * i + 2]; } return 0; }
+	memcpy(rgb, img, n * 3);
+	return 0;
+}
+
+/* cimbard_scan_extract_decode's extract half for a capture in `format` (cimbar_recv_js.cpp:160-179): get_rgb, then Extractor::extract */
+int co_extract_fmt(const uint8_t* img, int w, int h, int format, uint8_t* out1024, float* corners8)
+{
+	uint8_t* rgb = (uint8_t*)malloc((size_t)w * h * 3 + 1);
+	int rc = 0;
+	if (co_capture_to_rgb(img, w, h, format, rgb) == 0) rc = co_extract(rgb, w, h, out1024, corners8);
+	free(rgb);
+	return rc;
+}

@@ -51,7 +51,9 @@ typedef unsigned char uchar;
 
 namespace cv {
 
-enum { COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4, COLOR_RGBA2RGB = 1, COLOR_RGB2GRAY = 7 };
+// (imgproc.hpp ColorConversionCodes: COLOR_YUV420p2RGB is an alias of COLOR_YUV2RGB_YV12 -- the chroma plane that follows Y is read as V)
+enum { COLOR_BGR2RGB = 4, COLOR_RGB2BGR = 4, COLOR_RGBA2RGB = 1, COLOR_RGB2GRAY = 7, COLOR_YUV2RGB_NV12 = 90, COLOR_YUV2RGB_YV12 = 98,
+       COLOR_YUV2RGB_IYUV = 100, COLOR_YUV2RGB_I420 = COLOR_YUV2RGB_IYUV, COLOR_YUV420p2RGB = COLOR_YUV2RGB_YV12 };
 enum { ADAPTIVE_THRESH_MEAN_C = 0 };
 enum { THRESH_BINARY = 0, THRESH_OTSU = 8 };
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
@@ -159,6 +161,7 @@ inline Matx<T, M, N> operator*(const Matx<T, M, L>& a, const Matx<T, L, N>& b)
 template <typename T> class MatIterator_;
 template <typename T> class Mat_;
 template <typename T> class MatCommaInitializer_;
+class UMat;
 
 class Mat
 {
@@ -234,6 +237,7 @@ public:
 		for (int i = 0; i < rows; ++i) std::memmove(dst.ptr<uchar>(i), ptr<uchar>(i), (size_t)cols * elemSize());
 	}
 	void copyTo(Mat&& dst) const { Mat& d = dst; copyTo(d); }   // ROI temporaries: img.copyTo(canvas(Rect))
+	inline UMat getUMat(AccessFlag) const;                        // shares the pixels (cimbar_recv_js.cpp:101: cv::Mat(..).getUMat(ACCESS_RW).clone())
 
 	void push_back(const Mat& row)
 	{
@@ -273,8 +277,11 @@ class UMat : public Mat
 public:
 	UMat() {}
 	UMat(const Mat& m) : Mat(m) {}
+	UMat(int r, int c, int type) : Mat(r, c, type) {}
 	Mat getMat(AccessFlag) const { return *this; }
+	UMat clone() const { return UMat(Mat::clone()); }
 };
+inline UMat Mat::getUMat(AccessFlag) const { return UMat(*this); }
 inline UMat getUMat(const Mat& m, AccessFlag) { return UMat(m); }   // stands in for Mat::getUMat (cimbar.cpp:132: cv::imread(..).getUMat(ACCESS_RW)); shares the pixels
 
 template <typename T>
@@ -354,6 +361,51 @@ inline void cvtColor(const Mat& src_, Mat& dst, int code)
 			const uchar* s = src.ptr<uchar>(y);
 			uchar* d = out.ptr<uchar>(y);
 			for (int x = 0; x < src.cols; ++x) { d[3*x] = s[3*x+2]; d[3*x+1] = s[3*x+1]; d[3*x+2] = s[3*x]; }
+		}
+		dst = out;
+	}
+	else if (code == COLOR_YUV2RGB_NV12 || code == COLOR_YUV2RGB_YV12 || code == COLOR_YUV2RGB_IYUV)
+	{
+		// [assumed-OpenCV] color_yuv.simd.hpp, YUV 4:2:0 -> RGB (cvtColorTwoPlaneYUV2BGR / cvtColorThreePlaneYUV2BGR): the source is a one-channel
+		// Mat of height*3/2 rows (color.cpp asserts width % 2 == 0 && rows % 3 == 0); ITU-R BT.601 in 20-bit fixed point,
+		//   ruv = 2^19 + CVR*(v-128), guv = 2^19 + CVG*(v-128) + CUG*(u-128), buv = 2^19 + CUB*(u-128), y = max(0, Y-16)*CY,
+		//   c = saturate_cast<uchar>((y + cuv) >> 20)
+		// NV12: rows of interleaved (U, V) pairs behind the Y plane (uIdx 0). YV12 (= COLOR_YUV420p2RGB): a (w/2) x (h/2) V plane, then U;
+		// IYUV / I420: U, then V. The chroma planes are addressed the way YUV420p2RGB8Invoker does it (two chroma rows per Mat row of `step`
+		// bytes, the odd-quarter-height offset of cvtColorThreePlaneYUV2BGR), which for a continuous Mat is simply plane-contiguous.
+		if (src.type() != CV_8UC1 || src.cols % 2 != 0 || src.rows % 3 != 0) { std::cerr << "cv-shim: cvtColor YUV420: CV_8UC1, even width, rows % 3 == 0" << std::endl; std::abort(); }
+		const int W = src.cols, H = src.rows * 2 / 3;
+		const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SHIFT = 20;
+		Mat out(H, W, CV_8UC3);
+		const size_t stride = src.step;
+		const uchar* y0 = src.ptr<uchar>(0);
+		const uchar* p1 = y0 + stride * (size_t)H;                                                            // first chroma plane (or the UV rows)
+		const uchar* p2 = y0 + stride * (size_t)(H + H / 4) + (size_t)(W / 2) * ((H % 4) / 2);                 // second chroma plane
+		int step1 = 0, step2 = H % 4 == 2 ? 1 : 0;
+		const bool planar = code != COLOR_YUV2RGB_NV12;
+		const uchar* up = p1; const uchar* vp = p2; int us = step1, vs = step2;
+		if (code == COLOR_YUV2RGB_YV12) { std::swap(up, vp); std::swap(us, vs); }
+		const int uvsteps[2] = {W / 2, (int)stride - W / 2};
+		for (int j = 0; j < H; j += 2)
+		{
+			const uchar* ya = y0 + stride * (size_t)j;
+			const uchar* yb = ya + stride;
+			uchar* ra = out.ptr<uchar>(j);
+			uchar* rb = j + 1 < H ? out.ptr<uchar>(j + 1) : nullptr;
+			const uchar* uvrow = p1 + stride * (size_t)(j / 2);
+			for (int i = 0; i < W / 2; ++i)
+			{
+				const int u = planar ? up[i] : uvrow[2 * i], v = planar ? vp[i] : uvrow[2 * i + 1];
+				const int uu = u - 128, vv = v - 128;
+				const int ruv = (1 << (SHIFT - 1)) + CVR * vv, guv = (1 << (SHIFT - 1)) + CVG * vv + CUG * uu, buv = (1 << (SHIFT - 1)) + CUB * uu;
+				auto put = [&](uchar* d, int Y) {
+					const int y = std::max(0, Y - 16) * CY;
+					d[0] = saturate_u8((y + ruv) >> SHIFT); d[1] = saturate_u8((y + guv) >> SHIFT); d[2] = saturate_u8((y + buv) >> SHIFT);
+				};
+				put(ra + 6 * i, ya[2 * i]); put(ra + 6 * i + 3, ya[2 * i + 1]);
+				if (rb) { put(rb + 6 * i, yb[2 * i]); put(rb + 6 * i + 3, yb[2 * i + 1]); }
+			}
+			if (planar) { up += uvsteps[(us++) & 1]; vp += uvsteps[(vs++) & 1]; }
 		}
 		dst = out;
 	}

@@ -457,4 +457,16 @@ int ref_prethreshold_decode_test(unsigned* out3)
 	return good;
 }
 
+// cv::cvtColor of the cv-shim on a caller-described matrix (rows x cols x channels, 8-bit) -- the conversions get_rgb makes
+// (cimbar_js/cimbar_recv_js.cpp:94-120: COLOR_YUV2RGB_NV12 = 90, COLOR_YUV420p2RGB = 98, COLOR_RGBA2RGB = 1); out = rows_out x cols x 3.
+// The whole of get_rgb -> Extractor -> Decoder is reachable as the reference's own cimbard_scan_extract_decode, linked into this library.
+int ref_cvtcolor(const uint8_t* src, int rows, int cols, int channels, int code, uint8_t* out)
+{
+	cv::Mat m(rows, cols, CV_MAKETYPE(CV_8U, channels), (void*)src);
+	cv::Mat dst;
+	cv::cvtColor(m, dst, code);
+	for (int y = 0; y < dst.rows; ++y) std::memcpy(out + (size_t)y * dst.cols * dst.channels(), dst.ptr<uchar>(y), (size_t)dst.cols * dst.channels());
+	return dst.rows;
+}
+
 }  // extern "C"

@@ -1,7 +1,7 @@
 """GPU: the batch-parallel flood's certificate (k_flood_wave: "no tie-break of the reference's heap could have changed this frame's result")
 checked against the exact replay on ~100 000 distorted frames in three geometries, GPU vs GPU, through the library's own verify mode
 (CIMBAR_HIP_FLOOD_VERIFY=1: every certified frame is replayed exactly and compared cell by cell, CIMBAR_HIP_TAP_FLOOD_VERIFY) -- and the
-exact replay's kernels (k_flood3, k_flood2, k_flood) against each other and the oracle."""
+exact replay (k_flood3) against the oracle."""
 import os
 
 import numpy as np
@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from libcimbar_amd import decoder as D
-from libcimbar_amd import extractbench, framegen, geometry
+from libcimbar_amd import framegen, geometry
+from tools import extractbench
 from oracle import pyref
 from tests import frames as F
 
@@ -111,9 +112,11 @@ def camera_like(synth, n, seed):
     return out
 
 
-def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
-    """k_flood3, k_flood2 and the one-wavefront k_flood on shifted, noisy, rescaled, pure-noise and camera-like
-    frames, every flagged frame through the exact replay; two of the camera-like frames also against the oracle (the others GPU vs GPU)"""
+def test_exact_replay_kernel_against_the_oracle(synth):
+    """k_flood3 (the exact replay; the earlier generations k_flood / k_flood2 it was first checked against are gone) on shifted, noisy,
+    rescaled, pure-noise and camera-like frames, every flagged frame through the exact replay, with and without the sharpening threshold:
+    symbols, drifted positions, chunks and masks against the oracle's std::priority_queue-order restatement"""
+    from libcimbar_amd import modeb
     payload, fr = F.clean_frames(synth, 6, seed=606)
     g = np.random.default_rng(66)
     frames = [F.shift(fr[0], 2, 1), F.add_noise(F.shift(fr[1], -3, 2), 40, 7), F.rescale(fr[2], 6), g.integers(0, 256, (1024, 1024, 3), dtype=np.uint8),
@@ -121,39 +124,28 @@ def test_exact_replay_kernels_agree_with_each_other_and_the_oracle(synth):
     frames += camera_like(synth, 4, seed=607)
     frames = np.ascontiguousarray(np.stack(frames))
     n = len(frames)
-    outs = {}
-    for name, env in (("flood3", {}), ("flood2", {"CIMBAR_HIP_FLOOD3": "0"}), ("flood1", {"CIMBAR_HIP_FLOOD2": "0"})):
-        dec = decoder_with(dict(env, CIMBAR_HIP_FLOOD_WAVE="0"))
-        for pre in (0, 1):
-            dec.reset_ccm()
-            total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
-            outs[(name, pre)] = (chunks.copy(), masks.copy(), dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_FLOOD_PATH, n))
-        dec.close()
-    for pre in (0, 1):
-        ref = outs[("flood1", pre)]
-        assert (ref[4][:7] == 1).all()
-        for name in ("flood3", "flood2"):
-            o = outs[(name, pre)]
-            for k in range(n):
-                assert (o[2][k] == ref[2][k]).all(), f"{name} pre {pre} frame {k}: {(o[2][k] != ref[2][k]).sum()} symbols differ from the one-wavefront replay"
-                if ref[4][k]:
-                    assert (o[3][k] == ref[3][k]).all(), f"{name} pre {pre} frame {k}: drift differs"
-                assert o[1][k] == ref[1][k] and (o[0][k] == ref[0][k]).all()
-    # the camera-like frames against the oracle (sharpened, as the extractor's NEEDS_SHARPEN verdict would have it)
-    from libcimbar_amd import modeb
     xy = modeb.cell_positions()
-    o = outs[("flood3", 1)]
-    for k in (7, 8):
-        pyref.oracle_decode(frames[k], 1, 2, pyref.CoCcm())
-        wsym, wcol, wpos = pyref.oracle_stage()
-        assert (o[2][k] == wsym).all() and (xy + o[3][k].astype(np.int32) == wpos).all(), f"camera-like frame {k} differs from the oracle"
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0"})
+    for pre in (0, 1):
+        dec.reset_ccm()
+        total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
+        sym, drift, path = dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_DRIFT, n), dec.tap(D.TAP_FLOOD_PATH, n)
+        assert (path[:7] == 1).all()
+        ccm = pyref.CoCcm()
+        for k in range(n):
+            r, wchunks, wmask, ccm = pyref.oracle_decode(frames[k], pre, 2, ccm)
+            wsym, wcol, wpos = pyref.oracle_stage()
+            assert (sym[k] == wsym).all(), f"pre {pre} frame {k}: {(sym[k] != wsym).sum()} symbols differ from the oracle"
+            if path[k]:
+                assert (xy + drift[k].astype(np.int32) == wpos).all(), f"pre {pre} frame {k}: drifted positions differ"
+            assert masks[k] == wmask and (chunks[k] == wchunks).all(), (pre, k)
+    dec.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"CIMBAR_HIP_FLOOD3": "0"}], ids=["flood3", "flood2"])
-def test_exact_replay_kernels_with_the_heap_spilling(synth, env):
+def test_exact_replay_kernel_with_the_heap_spilling(synth):
     from libcimbar_amd import build as hipbuild
     from tests.test_gpu_flood import check, flood_frames
-    dec = decoder_with(dict(env, CIMBAR_HIP_FLOOD_WAVE="0"), lib_path=hipbuild.OUT_SPILLTEST)
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0"}, lib_path=hipbuild.OUT_SPILLTEST)
     frames, names = flood_frames(synth)
     frames = frames + camera_like(synth, 1, seed=608)
     check(dec, frames, names + ["camera-like"])

@@ -205,4 +205,20 @@ def test_files_of_every_kind_through_the_ingest_pipeline(tmp_path, synth, hip_de
     assert total == want_total and (masks == want_masks).all() and (chunks == want_chunks.reshape(12, -1)).all()
     if device_png:
         assert ing.host_decoded() == 9 and ing.png_stats()["refused_by_host_walk"] == 0 and ing.png_stats()["refused_by_device"] == 0
+        assert ing.fallback_overflow() == 0
+    ing.close()
+
+
+@pytest.mark.gpu
+def test_host_decoded_files_beyond_a_batchs_fallback_frames_are_counted_as_such(tmp_path, synth, hip_decoder):
+    """device PNG mode keeps 32 pinned frames per batch for files the kernels do not take; the 33rd such file of a batch is dropped -- and
+    reported by cimbar_ingest_fallback_overflow, not only as one more "refused" file"""
+    payload, frames = F.clean_frames(synth, 1, seed=89)
+    p = tmp_path / "f.jpg"
+    Image.fromarray(frames[0]).save(p, format="JPEG", quality=95, subsampling=0)
+    ing = ingest.Ingest(hip_decoder, threads=4, batch_frames=64, ring=2, png_device=True)
+    hip_decoder.reset_ccm()
+    total, chunks, masks = ing.run_files([str(p)] * 40)
+    assert ing.host_decoded() == 32 and ing.fallback_overflow() == 8 and ing.png_stats()["refused_by_host_walk"] == 8
+    assert int((masks == 0xFFF).sum()) == 32 and int((masks == 0).sum()) == 8
     ing.close()

@@ -4,7 +4,8 @@ workgroups per CU). Prints captures/s for K = 1, 2, 3 at 256 and 1024 captures p
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from libcimbar_amd import HipDecoder, extractbench, framegen, modeb
+from libcimbar_amd import HipDecoder, framegen, modeb
+from tools import extractbench
 
 dev = torch.device("cuda", 0)
 out = {}

@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-from . import framegen, modeb
+from libcimbar_amd import framegen, modeb
 
 QUADS = [((500, 40), (1480, 70), (470, 1030), (1500, 1000)), ((448, 28), (1472, 28), (448, 1052), (1472, 1052)),
          ((520, 60), (1450, 40), (540, 1010), (1430, 1040)), ((430, 30), (1500, 50), (450, 1060), (1470, 1040))]
@@ -47,14 +47,46 @@ def make_captures(frames, width=1920, height=1080, background=24):
     return out
 
 
-def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=None):
-    """sample: an empty dict; receives the first 32 captures (host) and what the GPU delivered for them, for the caller's CPU baseline"""
+def to_format(caps, fmt):
+    """RGB8 captures (n,h,w,3) on the device -> (n, bytes) in the C ABI's `fmt` (4 RGBA, 12 NV12, 420 = V plane then U plane, the order
+    cv::COLOR_YUV420p2RGB reads): an ordinary BT.601 limited-range forward conversion, chroma averaged over 2x2 (what a camera pipeline hands over)"""
+    n, h, w, _ = caps.shape
+    if fmt == 4:
+        out = torch.full((n, h, w, 4), 255, dtype=torch.uint8, device=caps.device)
+        out[..., :3] = caps
+        return out.reshape(n, -1)
+    out = torch.empty((n, h * w * 3 // 2), dtype=torch.uint8, device=caps.device)
+    for lo in range(0, n, 32):
+        f = caps[lo:lo + 32].to(torch.float32)
+        r, g, b = f[..., 0], f[..., 1], f[..., 2]
+        y = 16 + (65.481 * r + 128.553 * g + 24.966 * b) / 255
+        u = 128 + (-37.797 * r - 74.203 * g + 112.0 * b) / 255
+        v = 128 + (112.0 * r - 93.786 * g - 18.214 * b) / 255
+        m = f.shape[0]
+        sub = lambda c: c.reshape(m, h // 2, 2, w // 2, 2).mean(dim=(2, 4))
+        q = lambda c: c.round().clamp(0, 255).to(torch.uint8)
+        yq, uq, vq = q(y).reshape(m, -1), q(sub(u)), q(sub(v))
+        if fmt == 12:
+            out[lo:lo + m] = torch.cat([yq, torch.stack([uq, vq], dim=-1).reshape(m, -1)], dim=1)
+        else:
+            out[lo:lo + m] = torch.cat([yq, vq.reshape(m, -1), uq.reshape(m, -1)], dim=1)
+    return out
+
+
+ALGO_BYTES_PER_CAPTURE = {3: 1920 * 1080 * 3 + 7504, 4: 1920 * 1080 * 4 + 7504, 12: 1920 * 1080 * 3 // 2 + 7504, 420: 1920 * 1080 * 3 // 2 + 7504}
+
+
+def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=None, fmt=3):
+    """sample: an empty dict; receives the first 32 captures (host) and what the GPU delivered for them, for the caller's CPU baseline.
+    fmt: the capture format handed to the C ABI (cimbard_scan_extract_decode's `format`: 3 RGB, 4 RGBA, 12 NV12, 420)"""
     payload = framegen.synth_payload(n, seed=777, device=dev)
     frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
     dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), stream.cuda_stream)
     caps = make_captures(frames)
     del frames
     h, w = caps.shape[1:3]
+    if fmt != 3:
+        caps = to_format(caps, fmt).contiguous()
     chunks = torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev)
     masks = torch.zeros((n,), dtype=torch.int32, device=dev)
     status = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -67,12 +99,12 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=No
         dec.reset_ccm()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        dec.scan_extract_decode_device(caps.data_ptr(), w, h, n, chunks.data_ptr(), masks.data_ptr(), status.data_ptr(), -1, 2, stream.cuda_stream)
+        dec.scan_extract_decode_device(caps.data_ptr(), w, h, n, chunks.data_ptr(), masks.data_ptr(), status.data_ptr(), -1, 2, stream.cuda_stream, fmt=fmt)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         t0 = time.perf_counter()
-        lib.cimbar_hip_extract_batch(ctx, ctypes.c_void_p(caps.data_ptr()), w, h, n, 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(status.data_ptr()),
-                                     ctypes.c_void_p(corners.data_ptr()), 1, ctypes.c_void_p(stream.cuda_stream))
+        lib.cimbar_hip_extract_batch_fmt(ctx, ctypes.c_void_p(caps.data_ptr()), w, h, fmt, n, 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(status.data_ptr()),
+                                         ctypes.c_void_p(corners.data_ptr()), 1, ctypes.c_void_p(stream.cuda_stream))
         torch.cuda.synchronize(dev)
         de = time.perf_counter() - t0
         if _ == 0:
@@ -83,7 +115,7 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=No
     m = masks.cpu().numpy()
     if sample is not None:
         k = min(n, 32)
-        sample.update(captures=caps[:k].cpu().numpy(), chunks=chunks[:k].cpu().numpy(), masks=m[:k].copy(), status=st[:k].copy())
+        sample.update(captures=caps[:k].cpu().numpy(), chunks=chunks[:k].cpu().numpy(), masks=m[:k].copy(), status=st[:k].copy(), fmt=fmt, size=(w, h))
     full = (m == 0xFFF)
     payload_ok = bool((chunks[torch.from_numpy(full).to(dev)] == payload[torch.from_numpy(full).to(dev)]).all().item())
     path = dec.tap(7, n)
@@ -91,15 +123,52 @@ def run(dec, dev, stream, synth, n=256, reps=3, key="config5_extract", sample=No
     seen = info[info != 0xFFFFFFFF]
     rules = {str(int(r)): int(((seen & 0xFF) == r).sum()) for r in np.unique(seen & 0xFF)}
     declined = seen[(seen & 0xFF) != 0]
+    algo = ALGO_BYTES_PER_CAPTURE[fmt] if (w, h) == (1920, 1080) else None
     return {key: {
-        "captures": n, "size": [w, h], "ms": round(best_all * 1e3, 3), "captures_per_s": round(n / best_all, 1),
+        "captures": n, "size": [w, h], "format": fmt, "ms": round(best_all * 1e3, 3), "captures_per_s": round(n / best_all, 1),
+        # the chain's dominant kernel is the exact flood replay (k_flood3: one dependent chain per frame, latency-bound -- no HBM or FLOP roofline
+        # applies to it); what the whole chain makes of the HBM figure is stated so that the row can be read next to the headline's
+        "roofline": {"bound": "latency", "kernel": "k_flood3", "achieved": None if algo is None else round(algo * n / best_all / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                     "frac": None if algo is None else round(algo * n / best_all / 8e12, 5), "algorithmic_bytes": None if algo is None else algo * n,
+                     "basis": "whole chain (extract + decode) wall time; capture bytes in + chunks out", "traffic": None},
         "extract_only_ms": round(best_ext * 1e3, 3), "extract_only_captures_per_s": round(n / best_ext, 1),
         "extracted": int((st > 0).sum()), "needs_sharpen": int((st == 2).sum()), "frames_fully_decoded": int(full.sum()),
         "payload_ok_where_decoded": payload_ok, "flood_exact_frames": int((path == 1).sum()), "flood_batch_frames": int((path == 2).sum()),
         "flood_wave_outcome_by_rule": rules if seen.size else "certifying pass skipped by the scheduler for this batch (it certified < 1/16 of the batch before)",
         "flood_wave_declined_at": {"median_super_round": int(np.median((declined >> 8) & 0xFF)) if declined.size else None,
                                    "median_cells_decoded": int(np.median(declined >> 16)) if declined.size else None},
-        "note": "device-resident 1080p captures -> cimbar_hip_scan_extract_decode_batch (blur, Otsu, anchor search, warp, decode), preprocess = guess"}}
+        "note": "device-resident 1080p captures -> cimbar_hip_scan_extract_decode_batch_fmt (blur, Otsu, anchor search, warp, decode), preprocess = guess"}}
+
+
+def run_host_fed(dec, dev, stream, n=256, fmts=(3, 12), key="config5_host_fed"):
+    """captures in page-locked HOST memory -> cimbar_hip_scan_extract_decode_batch_fmt(host in, host out): one H2D copy of the captures as the
+    camera delivers them, the whole chain, chunks back -- cimbard_scan_extract_decode's own shape, n captures per call. PCIe carries
+    width * height * 3 bytes per RGB capture and half of that for NV12 / I420."""
+    payload = framegen.synth_payload(n, seed=778, device=dev)
+    frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
+    dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), stream.cuda_stream)
+    rgb = make_captures(frames)
+    del frames
+    h, w = rgb.shape[1:3]
+    rows = {}
+    for fmt in fmts:
+        caps = (rgb if fmt == 3 else to_format(rgb, fmt)).reshape(n, -1).cpu().pin_memory()
+        hv = caps.numpy()
+        dec.reset_ccm()
+        dec.scan_extract_decode_batch(hv[:8], preprocess=-1, size=(w, h), fmt=fmt)
+        best = None
+        for _ in range(3):
+            dec.reset_ccm()
+            t0 = time.perf_counter()
+            total, chunks, masks, status = dec.scan_extract_decode_batch(hv, preprocess=-1, size=(w, h), fmt=fmt)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        rows[str(fmt)] = {"ms": round(best * 1e3, 3), "captures_per_s": round(n / best, 1), "bytes_per_capture": int(hv.shape[1]),
+                          "pcie_GBs": round(hv.size / best / 1e9, 2), "extracted": int((status > 0).sum()), "frames_fully_decoded": int((masks == 0xFFF).sum())}
+        del caps, hv
+    return {key: {"captures": n, "size": [w, h], "by_format": rows,
+                  "note": "pinned host captures -> cimbar_hip_scan_extract_decode_batch_fmt (host in, host out), synchronous: H2D + extract + decode + D2H; "
+                          "format 3 = RGB8, 12 = NV12 (half the bytes over PCIe and out of HBM; converted inside the gray and warp kernels)"}}
 
 
 def run_stream(dev, n=1024, contexts=2, batches=6, reps=2, key="config5_stream_1024"):
@@ -107,7 +176,7 @@ def run_stream(dev, n=1024, contexts=2, batches=6, reps=2, key="config5_stream_1
     reference's CLI does with one Decoder per worker thread (cimbar.cpp: each thread owns its Extractor + Decoder, so the colour-correction
     carry-over is per worker there too). One batch's blur / anchor scan / warp / threshold then run while another batch's flood replay holds
     the chip's wavefront slots only thinly. Same captures as run(); throughput over `batches` back-to-back batches."""
-    from .decoder import HipDecoder
+    from libcimbar_amd.decoder import HipDecoder
     boot = HipDecoder(dev.index or 0)
     st0 = torch.cuda.current_stream(dev)
     payload = framegen.synth_payload(n, seed=777, device=dev)

@@ -6,7 +6,8 @@ import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from libcimbar_amd import HipDecoder, extractbench, framegen, modeb
+from libcimbar_amd import HipDecoder, framegen, modeb
+from tools import extractbench
 
 dev = torch.device("cuda", 0)
 dec = HipDecoder(0)

@@ -3,7 +3,8 @@ the two half-batches' flood kernels start and end. tools/gpu_flood_timeline.sh p
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from libcimbar_amd import HipDecoder, extractbench
+from libcimbar_amd import HipDecoder
+from tools import extractbench
 dev = torch.device("cuda", 0)
 dec = HipDecoder(0)
 st = torch.cuda.current_stream(dev)
