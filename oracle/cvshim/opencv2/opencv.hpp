@@ -26,7 +26,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -58,16 +60,22 @@ enum { ADAPTIVE_THRESH_MEAN_C = 0 };
 enum { THRESH_BINARY = 0, THRESH_OTSU = 8 };
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
 enum { DECOMP_LU = 0, DECOMP_SVD = 1 };
-enum AccessFlag { ACCESS_READ = 1 << 24, ACCESS_RW = 3 << 24 };
+enum AccessFlag { ACCESS_READ = 1 << 24, ACCESS_RW = 3 << 24, ACCESS_FAST = 1 << 26 };
 
 static inline int cvRound(double v) { return (int)lrint(v); }   // round-half-even under the default FP mode
 static inline int cvFloor(double v) { return (int)std::floor(v); }
 static inline uchar saturate_u8(int v) { return (uchar)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} };
+struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} bool operator==(const Size& o) const { return width == o.width && height == o.height; } };
 struct Point { int x = 0, y = 0; Point() {} Point(int x_, int y_) : x(x_), y(y_) {} };
 struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : x(x_), y(y_) {} };
-struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+struct Rect
+{
+	int x = 0, y = 0, width = 0, height = 0;
+	Rect() {}
+	Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
+	Rect(const Point& p, const Size& s) : x(p.x), y(p.y), width(s.width), height(s.height) {}
+};
 
 struct Scalar
 {
@@ -76,6 +84,8 @@ struct Scalar
 	Scalar(double a, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
 	double& operator[](int i) { return val[i]; }
 	const double& operator[](int i) const { return val[i]; }
+	bool operator==(const Scalar& o) const { return val[0] == o.val[0] && val[1] == o.val[1] && val[2] == o.val[2] && val[3] == o.val[3]; }
+	bool operator!=(const Scalar& o) const { return !(*this == o); }
 };
 
 struct Vec3b
@@ -324,6 +334,77 @@ protected:
 template <typename T, typename V>
 inline MatCommaInitializer_<T> operator<<(const Mat_<T>& m, V v) { return MatCommaInitializer_<T>(m, (T)v); }
 
+// ---------------------------------------------------------------- what the reference's unit tests use on top of the library code
+// [assumed-OpenCV] operator<<(ostream, Matx) = Formatter::FMT_DEFAULT: "[a, b, c;\n d, e, f]" with %.8g for float (%.16g for double)
+template <typename T, int M, int N>
+inline std::ostream& operator<<(std::ostream& os, const Matx<T, M, N>& m)
+{
+	os << "[";
+	for (int i = 0; i < M; ++i)
+	{
+		for (int j = 0; j < N; ++j)
+		{
+			char buf[64];
+			std::snprintf(buf, sizeof buf, sizeof(T) == 4 ? "%.8g" : "%.16g", (double)m(i, j));
+			os << buf;
+			if (j + 1 < N) os << ", ";
+		}
+		if (i + 1 < M) os << ";\n ";
+	}
+	return os << "]";
+}
+
+// cv::sum: per-channel sum of all elements
+inline Scalar sum(const Mat& m)
+{
+	Scalar s;
+	const int cn = m.channels();
+	for (int y = 0; y < m.rows; ++y)
+	{
+		const uchar* p = m.ptr<uchar>(y);
+		for (int x = 0; x < m.cols; ++x)
+			for (int c = 0; c < cn && c < 4; ++c) s[c] += p[x * cn + c];
+	}
+	return s;
+}
+// Mat != Mat (MatExpr compare): 255 where the elements differ, 0 where they are equal, same shape and channels
+inline Mat operator!=(const Mat& a, const Mat& b)
+{
+	Mat r(a.rows, a.cols, a.type());
+	const size_t n = (size_t)a.cols * a.elemSize();
+	for (int y = 0; y < a.rows; ++y)
+	{
+		const uchar* pa = a.ptr<uchar>(y); const uchar* pb = b.ptr<uchar>(y); uchar* pr = r.ptr<uchar>(y);
+		for (size_t i = 0; i < n; ++i) pr[i] = pa[i] != pb[i] ? 255 : 0;
+	}
+	return r;
+}
+
+// imwrite / imread: the reference's tests write a frame as PNG and read it back -- a LOSSLESS round trip, which is all the shim keeps of it: a private
+// container ("CVSHIMG1", rows, cols, channels, the pixels in the caller's channel order), whatever the path's extension says. A file that is not one
+// (a real PNG / JPEG: this image has no codec, and the reference's samples/ are not in /root/reference) reads as an empty Mat, like cv::imread of
+// a missing file.
+inline bool imwrite(const std::string& path, const Mat& m)
+{
+	std::ofstream f(path, std::ios::binary);
+	if (!f) return false;
+	const int32_t hdr[3] = {m.rows, m.cols, m.channels()};
+	f.write("CVSHIMG1", 8);
+	f.write((const char*)hdr, sizeof hdr);
+	for (int y = 0; y < m.rows; ++y) f.write((const char*)m.ptr<uchar>(y), (std::streamsize)((size_t)m.cols * m.elemSize()));
+	return f.good();
+}
+inline Mat imread(const std::string& path, int = 1)
+{
+	std::ifstream f(path, std::ios::binary);
+	char magic[8];
+	int32_t hdr[3];
+	if (!f || !f.read(magic, 8) || std::memcmp(magic, "CVSHIMG1", 8) != 0 || !f.read((char*)hdr, sizeof hdr)) return Mat();
+	Mat m(hdr[0], hdr[1], CV_MAKETYPE(CV_8U, hdr[2]));
+	f.read((char*)m.data, (std::streamsize)((size_t)hdr[0] * hdr[1] * hdr[2]));
+	return f ? m : Mat();
+}
+
 // ---------------------------------------------------------------- imgproc subset
 // [assumed-OpenCV] color_rgb.simd.hpp RGB2Gray<uchar>: 15-bit fixed point, R2Y=9798 G2Y=19235 B2Y=3735
 inline void cvtColor(const Mat& src_, Mat& dst, int code)
@@ -416,11 +497,54 @@ inline void cvtColor(const Mat& src_, Mat& dst, int code)
 	}
 }
 
-inline void resize(const Mat&, Mat&, Size)
+// [assumed-OpenCV] resize.cpp, INTER_LINEAR for CV_8U (resizeGeneric_ + HResizeLinear / VResizeLinear<uchar, int, short, FixedPtCast<.., 22>>):
+//   fx = (dx + 0.5) * (src.w / dst.w) - 0.5 (float); sx = floor(fx), fx -= sx; sx < 0 -> (0, fx 0); sx >= src.w - 1 -> (src.w - 1, fx 0)
+//   weights as shorts: saturate_cast<short>((1 - fx) * 2048), saturate_cast<short>(fx * 2048); horizontal pass in int, vertical pass
+//   dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2. (The exact-2x shrink, which OpenCV turns into INTER_AREA, is not taken by any caller.)
+inline void resize(const Mat& src_, Mat& dst, Size dsize, double = 0, double = 0, int = INTER_LINEAR)
 {
-	// only reached for tiles larger than 8x8 (average_hash.h:24); mode-B tiles are 8x8
-	std::cerr << "cv-shim: resize() is not part of the mode-B hot path" << std::endl;
-	std::abort();
+	Mat src = src_;
+	const int cn = src.channels(), sw = src.cols, sh = src.rows, dw = dsize.width, dh = dsize.height;
+	if (src.depth() != CV_8U || (sw == 2 * dw && sh == 2 * dh)) { std::cerr << "cv-shim: resize: CV_8U, INTER_LINEAR, not the exact 2x shrink" << std::endl; std::abort(); }
+	auto sat_short = [](float v) { int i = cvRound(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); };
+	std::vector<int> xofs(dw), yofs(dh);
+	std::vector<short> xa(2 * dw), ya(2 * dh);
+	const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+	for (int dx = 0; dx < dw; ++dx)
+	{
+		float fx = (float)((dx + 0.5) * scale_x - 0.5);
+		int sx = cvFloor(fx);
+		fx -= sx;
+		if (sx < 0) { fx = 0; sx = 0; }
+		if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+		xofs[dx] = sx; xa[2 * dx] = sat_short((1.f - fx) * 2048); xa[2 * dx + 1] = sat_short(fx * 2048);
+	}
+	for (int dy = 0; dy < dh; ++dy)
+	{
+		float fy = (float)((dy + 0.5) * scale_y - 0.5);
+		int sy = cvFloor(fy);
+		fy -= sy;
+		yofs[dy] = sy; ya[2 * dy] = sat_short((1.f - fy) * 2048); ya[2 * dy + 1] = sat_short(fy * 2048);
+	}
+	Mat out(dh, dw, src.type());
+	std::vector<int> r0((size_t)dw * cn), r1((size_t)dw * cn);
+	auto hrow = [&](int sy, std::vector<int>& row) {
+		sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);                     // (the vertical taps clip to the image: resizeGeneric_Invoker's clip())
+		const uchar* S = src.ptr<uchar>(sy);
+		for (int dx = 0; dx < dw; ++dx)
+		{
+			const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx;
+			for (int c = 0; c < cn; ++c) row[(size_t)dx * cn + c] = S[sx * cn + c] * xa[2 * dx] + S[sx1 * cn + c] * xa[2 * dx + 1];
+		}
+	};
+	for (int dy = 0; dy < dh; ++dy)
+	{
+		hrow(yofs[dy], r0); hrow(yofs[dy] + 1, r1);
+		uchar* D = out.ptr<uchar>(dy);
+		const int b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+		for (size_t i = 0; i < (size_t)dw * cn; ++i) D[i] = (uchar)((((b0 * (r0[i] >> 4)) >> 16) + ((b1 * (r1[i] >> 4)) >> 16) + 2) >> 2);
+	}
+	dst = out;
 }
 
 // [assumed-OpenCV] filter2D, ddepth=-1, 8u, float kernel, anchor centre, delta 0, BORDER_REFLECT_101;
