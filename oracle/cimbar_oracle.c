@@ -313,9 +313,16 @@ static void update_adjacents(const int adj[4], heap_t* hp, instr_t* ins, const u
 }
 
 /* lib/cimb_translator/CimbReader.cpp:139-162 read() driven to completion, with FloodDecodePositions.cpp:17-134 */
+/* statistics of the last co_symbol_pass on this thread (sizing of the GPU replay's LDS heap: tools/heap_peak.py): the largest number of live
+ * priority-queue entries and the number of pops */
+static __thread int g_heap_peak = 0, g_heap_pops = 0;
+int co_last_heap_peak(void) { return g_heap_peak; }
+int co_last_heap_pops(void) { return g_heap_pops; }
+
 int co_symbol_pass(const uint8_t* bitplane, int32_t* visit, uint8_t* dist)
 {
 	ensure_pos();
+	g_heap_peak = 0; g_heap_pops = 0;
 	instr_t* ins = (instr_t*)malloc(sizeof(instr_t) * NCELLS);
 	uint8_t* remaining = (uint8_t*)malloc(NCELLS);
 	heap_t hp = {0, 0, 0};
@@ -330,7 +337,9 @@ int co_symbol_pass(const uint8_t* bitplane, int32_t* visit, uint8_t* dist)
 
 	int count = 0;
 	while (count < NCELLS && hp.n > 0) {
+		if (hp.n > g_heap_peak) g_heap_peak = hp.n;
 		hent e = heap_pop(&hp);
+		++g_heap_pops;
 		int i = e.idx;
 		if (!remaining[i]) continue;
 		remaining[i] = 0;

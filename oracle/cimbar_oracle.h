@@ -107,6 +107,8 @@ void co_threshold_bitplane(const uint8_t* rgb, int w, int h, int preprocess, uin
  * visit[4*k+0..3] = cell index, drifted x, drifted y, symbol of the k-th decoded cell. dist (optional): error distance.
  * Returns the number of cells visited. */
 int co_symbol_pass(const uint8_t* bitplane, int32_t* visit, uint8_t* dist);
+int co_last_heap_peak(void);   /* of the last co_symbol_pass on this thread: most live queue entries / pops */
+int co_last_heap_pops(void);
 
 /* libcorrect decode.c:299-379 (correct_reed_solomon_decode), GF(2^8) poly 0x187, fcr 1, gap 1 */
 int co_rs_decode(const uint8_t* enc, unsigned enc_len, unsigned parity, uint8_t* msg);
