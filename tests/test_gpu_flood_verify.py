@@ -112,8 +112,10 @@ def camera_like(synth, n, seed):
     return out
 
 
-def test_exact_replay_kernel_against_the_oracle(synth):
-    """k_flood3 (the exact replay; the earlier generations k_flood / k_flood2 it was first checked against are gone) on shifted, noisy,
+@pytest.mark.parametrize("dense", [0, 1])
+def test_exact_replay_kernel_against_the_oracle(synth, dense):
+    """(dense = 1: the eight-frames-per-CU instance -- visited bits in LDS, offered priorities in global memory, 4 160-slot LDS heap, so the
+    shifted frames' heaps also cross into the spill area.) k_flood3 (the exact replay; the earlier generations k_flood / k_flood2 it was first checked against are gone) on shifted, noisy,
     rescaled, pure-noise and camera-like frames, every flagged frame through the exact replay, with and without the sharpening threshold:
     symbols, drifted positions, chunks and masks against the oracle's std::priority_queue-order restatement"""
     from libcimbar_amd import modeb
@@ -125,7 +127,7 @@ def test_exact_replay_kernel_against_the_oracle(synth):
     frames = np.ascontiguousarray(np.stack(frames))
     n = len(frames)
     xy = modeb.cell_positions()
-    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0"})
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": str(dense)})
     for pre in (0, 1):
         dec.reset_ccm()
         total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
@@ -142,10 +144,11 @@ def test_exact_replay_kernel_against_the_oracle(synth):
     dec.close()
 
 
-def test_exact_replay_kernel_with_the_heap_spilling(synth):
+@pytest.mark.parametrize("dense", [0, 1])
+def test_exact_replay_kernel_with_the_heap_spilling(synth, dense):
     from libcimbar_amd import build as hipbuild
     from tests.test_gpu_flood import check, flood_frames
-    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0"}, lib_path=hipbuild.OUT_SPILLTEST)
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": str(dense)}, lib_path=hipbuild.OUT_SPILLTEST)
     frames, names = flood_frames(synth)
     frames = frames + camera_like(synth, 1, seed=608)
     check(dec, frames, names + ["camera-like"])
