@@ -514,7 +514,8 @@ def extras(dec, dev, stream, n, outs, steps):
             torch.cuda.empty_cache()
         except Exception as e:
             out["config5_extract_nv12"] = {"error": repr(e)}
-        # larger batches: the replay's residency (frames per CU) is what bounds a batch's time
+        # larger batches: the replay's residency (frames per CU) is what bounds a batch's time. Above 1024 frames per launch the
+        # library runs the replay's dense instance (eight frames per CU: k_flood3<4095, true>)
         for big in (2048, 4096):
             try:
                 out.update(extractbench.run(dec, dev, stream, synth, n=big, reps=1, key=f"config5_extract_{big}"))
@@ -527,6 +528,10 @@ def extras(dec, dev, stream, n, outs, steps):
             out.update(extractbench.run_stream(dev, n=1024, contexts=2, batches=6, key="config5_stream_1024"))
             torch.cuda.empty_cache()
             out.update(extractbench.run_stream(dev, n=256, contexts=3, batches=12, key="config5_stream_256"))
+            torch.cuda.empty_cache()
+            out.update(extractbench.run_stream(dev, n=2048, contexts=2, batches=6, key="config5_stream_2048"))
+            torch.cuda.empty_cache()
+            out.update(extractbench.run_stream(dev, n=4096, contexts=2, batches=4, key="config5_stream_4096"))
             torch.cuda.empty_cache()
         except Exception as e:
             out["config5_stream_1024"] = {"error": repr(e)}
