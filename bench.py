@@ -63,15 +63,16 @@ def measured_traffic(kernel, n):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
         return None, None
-    try:
-        pmc = json.load(open(files[-1]))["pmc"]
-        key = {"threshold": "k_threshold<2, false>", "symbols": "k_symbols", "rs_symbols": "k_rs<4>", "rs_colors": "k_rs<2>",
-               "colors": "k_colors", "frame_mid": "k_frame_mid", "frame_end": "k_frame_end", "flood": "k_flood3"}[kernel]
-        c = pmc[key]
-        per_1024 = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        return per_1024 * n / 1024.0, os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    key = {"threshold": "k_threshold<2, false>", "symbols": "k_symbols", "rs_symbols": "k_rs<4>", "rs_colors": "k_rs<2>",
+           "colors": "k_colors", "frame_mid": "k_frame_mid", "frame_end": "k_frame_end", "flood": "k_flood3"}[kernel]
+    for path in reversed(files):      # the newest summary that holds this kernel's counters (summaries of other commands live there too)
+        try:
+            c = json.load(open(path))["pmc"][key]
+            per_1024 = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            return per_1024 * n / 1024.0, os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def usable_cpus():
