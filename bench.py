@@ -486,7 +486,7 @@ def extras(dec, dev, stream, n, outs, steps):
         import bench_config4 as config4
         torch.cuda.empty_cache()
         c4 = config4.bench(dec, dev, 0, 1, argparse.Namespace(frames=1024, steps=2, warmup=1))
-        out["config4_n1"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "stage_s", "decode_only_frames_per_s", "end_to_end_over_decode_only", "sink",
+        out["config4_n1"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "stage_s", "decode_only_frames_per_s", "end_to_end_over_decode_only", "without_solve", "sink",
                                                 "chunks_match_encoded_stream")}
         out["config4_n1"]["workload"] = c4["config"]["workload"]
         torch.cuda.empty_cache()

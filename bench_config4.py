@@ -92,7 +92,7 @@ def bench(dec, dev, rank, world, args, quiet=False):
         masks.zero_()
         torch.cuda.synchronize(dev)
         t = {}
-        res = {"fed": 0, "file_id": 0, "slabs_fed": 0, "sink_s": 0.0, "done_at_s": None}
+        res = {"fed": 0, "file_id": 0, "slabs_fed": 0, "sink_s": 0.0, "feed_s": 0.0, "solve_s": 0.0, "done_at_s": None}
         copied = [torch.cuda.Event() for _ in range(nslabs)] if rank == 0 else None
         issued = threading.Semaphore(0)
 
@@ -100,8 +100,9 @@ def bench(dec, dev, rank, world, args, quiet=False):
             # the consumer side of the reference's worker pool -> one sink (web/recv-worker.js:47-64; concurrent_fountain_decoder_sink.h:58-90)
             if ref is not None:
                 ref.ref_sink_reset(625)
-                ref.ref_sink_feed_batch.restype = ctypes.c_int64
+                ref.ref_sink_feed_batch_timed.restype = ctypes.c_int64
             fid = ctypes.c_uint32(0)
+            feed_s, solve_s = ctypes.c_double(0.0), ctypes.c_double(0.0)
             for s in range(nslabs):
                 issued.acquire()
                 if res["file_id"]:
@@ -111,8 +112,10 @@ def bench(dec, dev, rank, world, args, quiet=False):
                     continue
                 t0 = time.perf_counter()
                 hc, hm = h_chunks[s].numpy(), h_masks[s].numpy().view(np.uint32)
-                res["fed"] += int(ref.ref_sink_feed_batch(P(hc), P(hm), hc.shape[0], 12, 625, P(out), out.size, ctypes.byref(fid)))
+                res["fed"] += int(ref.ref_sink_feed_batch_timed(P(hc), P(hm), hc.shape[0], 12, 625, P(out), out.size, ctypes.byref(fid),
+                                                               ctypes.byref(feed_s), ctypes.byref(solve_s)))
                 res["sink_s"] += time.perf_counter() - t0
+                res["feed_s"], res["solve_s"] = feed_s.value, solve_s.value
                 res["slabs_fed"] += 1
                 if fid.value:
                     res["file_id"] = int(fid.value)
@@ -164,6 +167,8 @@ def bench(dec, dev, rank, world, args, quiet=False):
             th.join()
         t["total"] = time.perf_counter() - t_start
         t["sink_busy"] = res["sink_s"]
+        t["sink_feed"] = res["feed_s"]
+        t["sink_solve"] = res["solve_s"]
         return t, res
 
     def barrier():
@@ -241,11 +246,17 @@ def bench(dec, dev, rank, world, args, quiet=False):
         "stage_s": {k: round(v, 5) for k, v in acc.items()},
         "decode_only_frames_per_s": round(n_frames / d_only, 1),
         "end_to_end_over_decode_only": round((n_frames / per_step) / (n_frames / d_only), 3),
+        # the same with wirehair's solve (one call of the reference's sink, on one host thread, the same at every N) taken out of the step: what the
+        # decode + gather + copy + block-by-block feeding sustain -- the part of this row that can scale with the GPUs
+        "without_solve": {"ms_per_step": round((per_step - acc.get("sink_solve", 0.0)) * 1e3, 3),
+                          "frames_per_s": round(n_frames / max(per_step - acc.get("sink_solve", 0.0), 1e-9), 1),
+                          "over_decode_only": round(d_only / max(per_step - acc.get("sink_solve", 0.0), 1e-9), 3)},
         "sink": {"kind": "reference fountain_decoder_sink (oracle/_ref)" if ref is not None else None, "chunks_fed": res["fed"], "slabs_fed": res["slabs_fed"],
-                 "busy_s": round(res["sink_s"], 5), "file_complete_after_s": None if res["done_at_s"] is None else round(res["done_at_s"], 5),
+                 "busy_s": round(res["sink_s"], 5), "feed_s": round(res["feed_s"], 5), "solve_s": round(res["solve_s"], 5), "file_complete_after_s": None if res["done_at_s"] is None else round(res["done_at_s"], 5),
                  "chunks_per_s": round(res["fed"] / res["sink_s"], 1) if ref is not None and res["sink_s"] else None,
                  "file_recovered_sha256_match": sha_ok,
-                 "note": "wirehair's decode of the 27 104-block file is one sequential solve on one host thread: it is what the job waits for once the "
-                         "GPUs are done, at every N"},
+                 "note": "feed_s = the block-by-block calls (wirehair keeps its system up to date as blocks arrive), solve_s = the one call that completes "
+                         "the 27 104-block file: a sequential solve on one host thread, what the job waits for once the GPUs are done, at every N; "
+                         "feeding stops at that chunk"},
         "chunks_match_encoded_stream": ok_chunks,
     }
