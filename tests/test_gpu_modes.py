@@ -128,6 +128,30 @@ def test_flood_paths(dec67, synth67):
     assert set(path.tolist()) <= {1, 2} and path[0] == 2, path          # (which frames certify depends on the grid; the (2,1) shift does in both)
 
 
+def test_exact_replay_instances(synth67, MODE):
+    """every flagged frame through the exact replay, once with the instance batches of this size take and once with the dense one (eight frames
+    per CU: visited bits in LDS, priorities in global memory, heap levels 0-11 in LDS) -- the kernel is built per mode, the grid sizes differ"""
+    import os
+    _, frames = F.clean_frames(synth67, 4, seed=33)
+    fr = [F.shift(frames[0], 2, 1), F.shift(frames[1], -3, 2), F.add_noise(F.shift(frames[2], 1, -2), 50, 7), F.rescale(frames[3], 6)]
+    for dense in ("0", "1"):
+        old = {k: os.environ.get(k) for k in ("CIMBAR_HIP_FLOOD_WAVE", "CIMBAR_HIP_FLOOD_DENSE")}
+        os.environ.update(CIMBAR_HIP_FLOOD_WAVE="0", CIMBAR_HIP_FLOOD_DENSE=dense)
+        try:
+            dec = D.HipDecoder(0, MODE)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            check(dec, fr)
+            assert (dec.tap(D.TAP_FLOOD_PATH, 4) == 1).all()
+        finally:
+            dec.close()
+
+
 def test_decode_plain_matches_oracle(dec67, synth67, MODE):
     payload, frames = F.clean_frames(synth67, 3, seed=77)
     frames = [frames[0], F.add_noise(frames[1], 120, 2), F.blank_region(frames[2], 200, 330, 0, 1024)]
