@@ -283,6 +283,23 @@ def extras(dec, dev, stream, n, outs, steps):
         out["host_fed"] = {"frames": m, "ms": round(best * 1e3, 3), "frames_per_s": round(m / best, 1),
                            "pcie_GBs": round(m * modeb.FRAME_RGB_BYTES / best / 1e9, 2), "payload_ok": ok,
                            "note": "pinned host memory -> cimbar_hip_decode_batch(host in, host out): one H2D copy + decode + D2H, synchronous"}
+        # ---- one frame per call, the shape of the reference's own decode loop (cimbar.cpp:124-171: Decoder::decode_fountain per image): a host
+        # frame in, its chunks out, synchronous -- latency, not throughput; next to the reference's single-thread figure of cpu_baseline
+        try:
+            k = 64
+            for q in range(8):
+                dec.decode_frame(hv[q])
+            t0 = time.perf_counter()
+            good = 0
+            for q in range(k):
+                r, c1, m1 = dec.decode_frame(hv[q])
+                good += int(r)
+            dt = (time.perf_counter() - t0) / k
+            out["single_frame"] = {"frames": k, "ms_per_frame": round(dt * 1e3, 4), "frames_per_s": round(1.0 / dt, 1), "all_bytes_good": good == k * 7500,
+                                   "note": "cimbar_hip_decode_frame: one pinned host frame in (H2D), eight kernels, chunks + mask back (D2H), one call "
+                                           "per frame on one context -- what a drop-in Decoder::decode_fountain call costs"}
+        except Exception as e:
+            out["single_frame"] = {"error": repr(e)}
         del host, hv
     except Exception as e:
         out["host_fed"] = {"error": repr(e)}
