@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     dev = torch.device("cuda", 0)
     if contexts <= 1:
         dec = HipDecoder(0)
-        r = extractbench.run(dec, dev, torch.cuda.current_stream(dev), None, n=n, reps=2, key="r")["r"]
+        r = extractbench.run(dec, dev, torch.cuda.current_stream(dev), None, n=n, reps=2, key="r", fmt=int(os.environ.get("PROBE_FMT", "3")))["r"]
         print("ROW", json.dumps({k: r[k] for k in ("captures", "ms", "captures_per_s", "extract_only_ms", "frames_fully_decoded", "payload_ok_where_decoded", "flood_exact_frames")}))
     else:
         r = extractbench.run_stream(dev, n=n, contexts=contexts, batches=6, reps=2, key="r")["r"]
