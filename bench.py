@@ -557,6 +557,22 @@ def extras(dec, dev, stream, n, outs, steps):
         pass
     except Exception as e:
         out["config5_extract"] = {"error": repr(e)}
+    # every row that names what bounds it gets a `roofline` object in the headline's shape (host-fed rows: the PCIe link, 64 GB/s for the
+    # Gen5 x16 of these boxes; device-PNG ingest: the inflate kernels, scalar-unit bound -- their HBM figure is stated so that the rows read alike)
+    PCIE_GBS = 64.0
+    for key in ("host_fed", "ingest_raw", "ingest_pinned"):
+        row = out.get(key)
+        if isinstance(row, dict) and "pcie_GBs" in row and "roofline" not in row:
+            row["roofline"] = {"bound": "pcie", "kernel": None, "achieved": row["pcie_GBs"], "peak": PCIE_GBS, "unit": "GB/s",
+                               "frac": round(row["pcie_GBs"] / PCIE_GBS, 4), "basis": "frame bytes host -> device per second of the whole call", "traffic": None}
+    for key in ("ingest_png_device", "ingest_png_device_cv_writer"):
+        row = out.get(key)
+        if isinstance(row, dict) and "frames_per_s" in row and "roofline" not in row:
+            algo = (row.get("pcie_bytes_per_frame") or row.get("avg_png_bytes") or 0) + 2 * (modeb.FRAME_RGB_BYTES + modeb.IMG) + modeb.FRAME_RGB_BYTES
+            gbs = algo * row["frames_per_s"] / 1e9
+            row["roofline"] = {"bound": "salu", "kernel": "k_png_inflate* (device-chosen) + k_png_unfilter, then the decode chain", "achieved": round(gbs, 2), "peak": 8000.0,
+                               "unit": "GB/s", "frac": round(gbs / 8000.0, 5),
+                               "basis": "compressed bytes in + filtered scanlines out and in again + RGB out + RGB into the decoder, per second of the whole run", "traffic": None}
     return out
 
 
