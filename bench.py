@@ -576,6 +576,91 @@ def extras(dec, dev, stream, n, outs, steps):
     return out
 
 
+def summary(line):
+    """The secondary rows in one small object, printed as the LAST key of the JSON line so that a tail of the output still holds them."""
+    ex = line.get("extra") or {}
+
+    def get(key, field):
+        row = ex.get(key)
+        return row.get(field) if isinstance(row, dict) else None
+    c4 = ex.get("config4_n1") if isinstance(ex.get("config4_n1"), dict) else {}
+    ws = c4.get("without_solve")
+    return {
+        "configs1_ms_per_step": line.get("ms_per_step"), "configs1_k1_frac": (line.get("roofline") or {}).get("frac"),
+        "configs1_whole_path_frac": (line.get("roofline") or {}).get("whole_path_frac"),
+        "configs2_ms_per_step": get("config3_cell_errors", "ms_per_step"),
+        "configs3_n1_frames_per_s": c4.get("value"), "configs3_n1_without_solve": ws.get("frames_per_s") if isinstance(ws, dict) else ws,
+        "configs4_captures_per_s": {"256": get("config5_extract", "captures_per_s"), "1024": get("config5_extract_1024", "captures_per_s"),
+                                    "1024_nv12": get("config5_extract_nv12", "captures_per_s"), "2048": get("config5_extract_2048", "captures_per_s"),
+                                    "4096": get("config5_extract_4096", "captures_per_s"), "stream_2048": get("config5_stream_2048", "captures_per_s"),
+                                    "stream_4096": get("config5_stream_4096", "captures_per_s")},
+        "png_files_to_chunks_frames_per_s": {"pillow": get("ingest_png_device", "frames_per_s"), "cv_writer": get("ingest_png_device_cv_writer", "frames_per_s")},
+        "png_kernels_images_per_s": {"pillow": get("png_device_kernels", "images_per_s"), "cv_writer": get("png_device_kernels_cv_writer", "images_per_s")},
+        "single_frame_ms": get("single_frame", "ms_per_frame"), "single_frame_overlapped_frames_per_s": get("single_frame_overlapped", "frames_per_s"),
+        "host_fed_frames_per_s": get("host_fed", "frames_per_s"),
+        "mode_k1_frac": {str(m): get("mode%d" % m, "threshold_hbm_frac") for m in (67, 66, 4, 8)},
+        "cpu_baseline_frames_per_s": (line.get("cpu_baseline") or {}).get("value"),
+    }
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """GPUs this process could open, WITHOUT creating a HIP context in the parent (the ranks it starts must be the first to touch their device)."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def self_launch(n, argv, check_gpus=True):
+    """`python bench.py --gpus N` without a launcher around it: re-run this file as N ranks under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1), which is the command the driver itself uses for N > 1. Returns the exit code of the job. With fewer than N
+    GPUs visible nothing is started: a 1-GPU number must never be printed for an N-GPU request."""
+    if check_gpus:
+        have = visible_gpus()
+        if have < n:
+            print(f"bench: needs {n} GPUs, found {have}", file=sys.stderr, flush=True)
+            return 3
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    print("bench: starting " + " ".join(cmd[1:]), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(rank, local_rank, world):
+    """--launch-check: the ranks exist, know who they are and can reach each other -- over gloo, no GPU touched. Rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    me = {"rank": rank, "local_rank": local_rank, "world_size": world, "pid": os.getpid(),
+          "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}}
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        ok = int(t.item()) == world * (world + 1) // 2 and sorted(e["rank"] for e in everyone) == list(range(world)) \
+            and sorted(e["local_rank"] for e in everyone) == list(range(world))
+        dist.destroy_process_group()
+    else:
+        everyone, ok = [me], True
+    if rank == 0:
+        print(json.dumps({"launch_check": "ok" if ok else "FAILED", "n_ranks": world, "ranks": everyone}), flush=True)
+    return 0 if ok else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -592,15 +677,27 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one ordinary call per step instead of the pipelined entry point (kernels of different steps never overlap: "
                          "what tools/gpu_profile.sh uses so that every traced dispatch is one kernel running alone)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher self-test, touches no GPU: start the --gpus ranks exactly as a measurement would, rendezvous them over gloo on "
+                         "127.0.0.1, and print one JSON line with every rank's RANK / LOCAL_RANK / WORLD_SIZE")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` (the shape of the driver's N = 1 command) IS the N-rank job: one process per GPU, started here
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], check_gpus=not args.launch_check))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never an n_gpus line for another N than the one asked for
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: start exactly one rank per requested GPU "
+                         f"(`python bench.py --gpus {args.gpus}` does that by itself)")
+    if args.launch_check:
+        raise SystemExit(launch_check(rank, local_rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench: needs {world} GPUs, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # the decoder's streams are created first, right behind the null stream: how streams fall onto the runtime's hardware queues
@@ -733,6 +830,7 @@ def main():
                        "input": f"{R} distinct synthetic batches decoded in rotation (no step is fed from L2 / Infinity Cache)",
                        "frames_per_gpu_per_step": n, "distinct_input_batches": R,
                        "exchange": exchange_name,
+                       "exchange_ranks": getattr(exchange, "nranks", None),          # ncclCommCount of the library's communicator (None at N = 1: no exchange)
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
                                       ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -760,6 +858,7 @@ def main():
             torch.cuda.empty_cache()
             line["extra"] = extras(dec, dev, stream, n, outs, max(20, args.steps // 4))
     if rank == 0:
+        line["summary"] = summary(line)          # last key: the driver keeps the tail of the line
         print(json.dumps(line), flush=True)
     if world > 1:
         if exchange is not None:

@@ -238,11 +238,14 @@ int64_t cimbar_hip_scan_extract_decode_batch_fmt(cimbar_hip_ctx* ctx, const uint
  *                     inside the caller's own group). devices NULL = 0..ndev-1. Fills out[0..ndev).
  *   comm_unique_id / comm_init_rank : one process per GPU; rank 0 makes the 128-byte id and hands it to the others by its own means.
  *   gather_chunks   : chunks / masks: this rank's n frames (device memory); all_chunks / all_masks: nranks * n frames on root (device
- *                     memory, may be NULL elsewhere). Enqueued on hip_stream; returns 0. */
+ *                     memory, may be NULL elsewhere). Enqueued on hip_stream; returns 0.
+ *   comm_info       : the communicator's size and this member's rank as RCCL reports them (ncclCommCount / ncclCommUserRank): what a
+ *                     benchmark line quotes so that it says itself how many ranks the exchange ran over. */
 typedef struct cimbar_hip_comm cimbar_hip_comm;
 int cimbar_hip_comm_init_all(int ndev, const int* devices, cimbar_hip_comm** out);
 int cimbar_hip_comm_unique_id(uint8_t id128[128]);
 int cimbar_hip_comm_init_rank(const uint8_t id128[128], int nranks, int rank, int device, cimbar_hip_comm** out);
+int cimbar_hip_comm_info(cimbar_hip_comm* comm, int* nranks, int* rank);
 void cimbar_hip_comm_destroy(cimbar_hip_comm* comm);
 int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int root, const uint8_t* chunks, const uint32_t* masks, int n,
                              uint8_t* all_chunks, uint32_t* all_masks, void* hip_stream);

@@ -27,7 +27,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
-    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
+    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_info", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
     "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
     "cimbar_hip_ctx_bufsize", "cimbar_hip_set_ccm",
     "cimbar_hip_capture_bytes", "cimbar_hip_scan_preprocess_fmt", "cimbar_hip_deskew_batch_fmt", "cimbar_hip_extract_batch_fmt",
@@ -108,6 +108,8 @@ def load_library(path=None):
     lib.cimbar_hip_comm_unique_id.restype = i32
     lib.cimbar_hip_comm_init_rank.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
     lib.cimbar_hip_comm_init_rank.restype = i32
+    lib.cimbar_hip_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.cimbar_hip_comm_info.restype = i32
     lib.cimbar_hip_comm_destroy.argtypes = [vp]
     lib.cimbar_hip_comm_destroy.restype = None
     lib.cimbar_hip_gather_chunks.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
@@ -227,6 +229,15 @@ def comm_unique_id():
     if rc != 0:
         raise CimbarHipError(f"cimbar_hip_comm_unique_id failed: {rc} (RCCL not available?)")
     return bytes(buf)
+
+
+def comm_info(comm):
+    """(nranks, rank) of a communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank)"""
+    n, r = ctypes.c_int32(0), ctypes.c_int32(-1)
+    rc = load_library().cimbar_hip_comm_info(comm, ctypes.byref(n), ctypes.byref(r))
+    if rc != 0:
+        raise CimbarHipError(f"cimbar_hip_comm_info failed: {rc}")
+    return int(n.value), int(r.value)
 
 
 def comm_destroy(comm):

@@ -75,6 +75,10 @@ class LibraryGather:
         if isinstance(box[0], Exception):
             raise RuntimeError(f"rank 0 could not create a communicator id: {box[0]!r}")
         self.comm = dec.comm_init_rank(box[0], self.world, self.rank)
+        # what RCCL says about the communicator it built (ncclCommCount / ncclCommUserRank): the bench line quotes THIS, not the launcher's WORLD_SIZE
+        self.nranks, self.comm_rank = _d.comm_info(self.comm)
+        if (self.nranks, self.comm_rank) != (self.world, self.rank):
+            raise RuntimeError(f"RCCL communicator has {self.nranks} ranks (this one {self.comm_rank}), the job has {self.world} (this one {self.rank})")
         self.stream = torch.cuda.Stream(dev)
 
     def __call__(self, chunks, masks, dst=0, group=None, out=None, async_op=True):

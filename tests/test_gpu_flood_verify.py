@@ -144,6 +144,42 @@ def test_exact_replay_kernel_against_the_oracle(synth, dense):
     dec.close()
 
 
+def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroups(synth):
+    """CIMBAR_HIP_FLOOD_DENSE_GRID=8 with 30 shifted / rescaled / noisy frames: the launch has 8 workgroups, so 22 frames are handed out through the
+    global counter pair (FloodScratch::next, zeroed by the host in front of the launch). Twice on the same context (the second launch must start
+    from a zero counter again), every frame against the oracle."""
+    payload, fr = F.clean_frames(synth, 6, seed=616)
+    g = np.random.default_rng(617)
+    frames = []
+    for k in range(30):
+        base = fr[k % 6]
+        kind = k % 3
+        if kind == 0:
+            frames.append(F.shift(base, int(g.integers(-6, 7)), int(g.integers(-6, 7)) or 1))
+        elif kind == 1:
+            frames.append(F.add_noise(F.shift(base, int(g.integers(-3, 4)) or 2, int(g.integers(-3, 4))), 35, 100 + k))
+        else:
+            frames.append(F.rescale(base, int(g.integers(3, 12))))
+    frames = np.ascontiguousarray(np.stack(frames))
+    n = len(frames)
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": "1", "CIMBAR_HIP_FLOOD_DENSE_GRID": "8"})
+    want = []
+    ccm = pyref.CoCcm()
+    for k in range(n):
+        r, wchunks, wmask, ccm = pyref.oracle_decode(frames[k], 0, 2, ccm)
+        want.append((wchunks.copy(), wmask, pyref.oracle_stage()[0].copy()))
+    for rep in range(2):
+        dec.reset_ccm()
+        total, chunks, masks = dec.decode_batch(frames)
+        sym, path = dec.tap(D.TAP_SYMBOLS, n), dec.tap(D.TAP_FLOOD_PATH, n)
+        assert (path == 1).sum() >= 24, "most frames were meant to take the exact replay (8 workgroups: the rest are handed out by the counter)"
+        for k in range(n):
+            wchunks, wmask, wsym = want[k]
+            assert (sym[k] == wsym).all(), f"launch {rep} frame {k}: {(sym[k] != wsym).sum()} symbols differ from the oracle"
+            assert masks[k] == wmask and (chunks[k] == wchunks).all(), (rep, k)
+    dec.close()
+
+
 @pytest.mark.parametrize("dense", [0, 1])
 def test_exact_replay_kernel_with_the_heap_spilling(synth, dense):
     from libcimbar_amd import build as hipbuild
