@@ -359,6 +359,14 @@ class HipDecoder:
         cimbar_hip_capture_bytes(w, h, fmt) bytes each as an (n, bytes) array. Returns (array, n, w, h, fmt)."""
         captures = np.ascontiguousarray(captures, dtype=np.uint8)
         if size is None:
+            fmt = int(fmt) if int(fmt) > 0 else 3          # (<= 0 means RGB to the C ABI as well, cimbar_recv_js.cpp:150-151)
+            if fmt == 4 and captures.ndim == 4 and captures.shape[3] == 4:
+                n, h, w = captures.shape[:3]
+                return captures, n, w, h, 4
+            if fmt != 3:
+                raise CimbarHipError(f"captures in format {fmt} need size=(w, h): the array's shape does not say what the frame is")
+            if captures.ndim != 4 or captures.shape[3] != 3:
+                raise CimbarHipError(f"RGB captures are an (n, h, w, 3) array, got {captures.shape}")
             n, h, w = captures.shape[:3]
             return captures, n, w, h, 3
         w, h = size

@@ -100,3 +100,22 @@ def test_oracle_capture_chain_equals_cimbard_scan_extract_decode(oracle, ref, sy
     blank = np.full(CF.capture_bytes(640, 480, fmt), 16 if fmt in (12, 420) else 0, np.uint8)
     assert reference_capture_chain(ref, blank, 640, 480, fmt)[0] == -3
     assert oracle_capture_chain(oracle, blank, 640, 480, fmt, pyref.CoCcm())[0] == -3
+
+
+def test_python_wrapper_refuses_a_format_its_array_cannot_describe():
+    """HipDecoder._captures without size=: RGB from an (n,h,w,3) array, RGBA from (n,h,w,4); NV12 / 4:2:0 planes need size=(w,h) -- never a
+    silent decode of another format's bytes as RGB."""
+    from libcimbar_amd import decoder as D
+
+    class Stub:
+        pass
+    stub = Stub()
+    rgb = np.zeros((2, 8, 16, 3), np.uint8)
+    arr, n, w, h, fmt = D.HipDecoder._captures(stub, rgb, None, 3)
+    assert (n, w, h, fmt) == (2, 16, 8, 3)
+    assert D.HipDecoder._captures(stub, rgb, None, 0)[4] == 3          # <= 0 is RGB, as in the C ABI
+    rgba = np.zeros((2, 8, 16, 4), np.uint8)
+    assert D.HipDecoder._captures(stub, rgba, None, 4)[1:] == (2, 16, 8, 4)
+    for bad_fmt, bad in ((12, rgb), (420, rgb), (4, rgb), (3, rgba), (12, np.zeros((2, 8 * 16 * 3 // 2), np.uint8))):
+        with pytest.raises(D.CimbarHipError):
+            D.HipDecoder._captures(stub, bad, None, bad_fmt)

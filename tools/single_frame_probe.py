@@ -29,3 +29,23 @@ t0 = time.perf_counter()
 for q in range(64):
     dec.decode_batch_device(d.data_ptr(), 1, ch.data_ptr(), ms.data_ptr(), False, 2, st); torch.cuda.synchronize()
 print("device-resident n=1 call+sync:", round((time.perf_counter() - t0) / 64 * 1e3, 4), "ms")
+# ---- what the call is made of: the H2D copy alone, the two D2H copies alone, a stream sync behind nothing
+hf = torch.from_numpy(frames[:1])          # pinned
+dd = torch.empty_like(d)
+for q in range(4): dd.copy_(hf, non_blocking=True); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for q in range(64): dd.copy_(hf, non_blocking=True); torch.cuda.synchronize()
+print("H2D 3 MB pinned copy+sync:", round((time.perf_counter() - t0) / 64 * 1e3, 4), "ms")
+hc = torch.empty((1, 7500), dtype=torch.uint8).pin_memory(); hm = torch.empty((1,), dtype=torch.int32).pin_memory()
+for q in range(4): hc.copy_(ch, non_blocking=True); hm.copy_(ms, non_blocking=True); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for q in range(64): hc.copy_(ch, non_blocking=True); hm.copy_(ms, non_blocking=True); torch.cuda.synchronize()
+print("two D2H copies + sync:", round((time.perf_counter() - t0) / 64 * 1e3, 4), "ms")
+t0 = time.perf_counter()
+for q in range(64): hm.copy_(ms, non_blocking=True); torch.cuda.synchronize()
+print("one 4-byte D2H + sync:", round((time.perf_counter() - t0) / 64 * 1e3, 4), "ms")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for q in range(64): dec.decode_batch_device(d.data_ptr(), 1, ch.data_ptr(), ms.data_ptr(), False, 2, st)
+e1.record(); torch.cuda.synchronize()
+print("device-resident n=1, 64 calls back to back, GPU time per call:", round(e0.elapsed_time(e1) / 64, 4), "ms")
