@@ -100,6 +100,24 @@ const char* cimbar_hip_last_error(const cimbar_hip_ctx* ctx);
 int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
                             int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask);
 
+/* The same call with frames in flight -- the shape of the reference's decode loop (cimbar.cpp:124-171: one Decoder::decode_fountain per image,
+ * the next image being read while this one decodes) and of web/recv-worker.js's frames-keep-arriving loop: frame k+1's host-to-device copy
+ * runs beside frame k's kernels, so one context sustains the PCIe copy rate instead of copy + kernels + copy-back per frame.
+ *   cimbar_hip_decode_frame_async : starts the frame and returns a ticket >= 0 (negative: an error code, nothing started). At most
+ *                     cimbar_hip_pipeline_depth(ctx) frames are in flight; starting one more first completes the oldest (its chunks and mask land
+ *                     in the buffers it was started with; its return value stays available to _wait for the next 16 tickets).
+ *                     `rgb` in page-locked memory (hipHostMalloc / hipHostRegister) is copied from where it lies and must stay untouched until the
+ *                     frame's _wait; pageable memory is copied to the context's page-locked staging before the call returns and may be reused or
+ *                     freed at once. `chunks` / `good_mask` are written by _wait (or by the completion described above), never before.
+ *                     Images of another size than the frame (CimbReader.cpp:107-126's padded / too-small cases) are decoded synchronously behind
+ *                     everything in flight and still get a ticket.
+ *   cimbar_hip_decode_frame_wait  : blocks until that frame is complete and returns what cimbar_hip_decode_frame would have returned.
+ * Frames are decoded in ticket order (the colour-correction matrix carries over from frame to frame exactly as in the synchronous call), so
+ * waiting in ticket order hands the chunks to a sink in the order the reference's loop would. cimbar_hip_decode_frame IS _async + _wait. */
+long long cimbar_hip_decode_frame_async(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
+                                        int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask);
+int cimbar_hip_decode_frame_wait(cimbar_hip_ctx* ctx, long long ticket);
+
 /* The same for `n` independent frames, decoded in frame order (frame f's CCM carry-over sees frames < f).
  *   rgb        : n densely packed 1024*1024*3 frames, in host or device memory (rgb_mem)
  *   chunks     : n*7500 bytes, masks: n words, in host or device memory (out_mem)

@@ -22,6 +22,7 @@ TAP_BITPLANE, TAP_SYMBOLS, TAP_COLORS, TAP_DRIFT, TAP_RS_OK, TAP_FLOOD, TAP_CCM,
 # every symbol include/cimbar_hip.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
 EXPORTS = (
     "cimbar_hip_create", "cimbar_hip_destroy", "cimbar_hip_bufsize", "cimbar_hip_last_error", "cimbar_hip_decode_frame",
+    "cimbar_hip_decode_frame_async", "cimbar_hip_decode_frame_wait",
     "cimbar_hip_decode_batch", "cimbar_hip_reset_ccm", "cimbar_hip_get_ccm", "cimbar_hip_tap", "cimbar_hip_enable_timing",
     "cimbar_hip_stage_times", "cimbar_hip_set_template", "cimbar_hip_encode_batch", "cimbar_hip_decode_plain_batch",
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
@@ -74,6 +75,10 @@ def load_library(path=None):
     lib.cimbar_hip_last_error.restype = ctypes.c_char_p
     lib.cimbar_hip_decode_frame.argtypes = [vp, vp, u32, u32, sz, i32, i32, vp, ctypes.POINTER(ctypes.c_uint32)]
     lib.cimbar_hip_decode_frame.restype = i32
+    lib.cimbar_hip_decode_frame_async.argtypes = [vp, vp, u32, u32, sz, i32, i32, vp, ctypes.POINTER(ctypes.c_uint32)]
+    lib.cimbar_hip_decode_frame_async.restype = ctypes.c_longlong
+    lib.cimbar_hip_decode_frame_wait.argtypes = [vp, ctypes.c_longlong]
+    lib.cimbar_hip_decode_frame_wait.restype = i32
     lib.cimbar_hip_decode_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.cimbar_hip_decode_batch.restype = i64
     lib.cimbar_hip_decode_plain_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
@@ -295,6 +300,32 @@ class HipDecoder:
                                                int(bool(should_preprocess)), int(color_correction), chunks.ctypes.data,
                                                ctypes.byref(mask))
         self._check(rc, "cimbar_hip_decode_frame")
+        return rc, chunks, mask.value
+
+    def decode_frame_async(self, rgb, should_preprocess=False, color_correction=2):
+        """Starts one frame (cimbar_hip_decode_frame_async) and returns a ticket for decode_frame_wait; up to pipeline_depth frames in flight, the
+        next frame's host-to-device copy running beside this one's kernels. `rgb` must stay alive and untouched until the wait when it is
+        page-locked memory (the array is kept referenced here either way)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise CimbarHipError("decode_frame_async: expected an HxWx3 uint8 image")
+        chunks = np.zeros((self.geo.CHUNKS_PER_FRAME, self.geo.CHUNK), dtype=np.uint8)
+        mask = ctypes.c_uint32(0)
+        t = self._lib.cimbar_hip_decode_frame_async(self._ctx, rgb.ctypes.data, rgb.shape[1], rgb.shape[0], rgb.strides[0],
+                                                    int(bool(should_preprocess)), int(color_correction), chunks.ctypes.data, ctypes.byref(mask))
+        self._check(t, "cimbar_hip_decode_frame_async")
+        if not hasattr(self, "_frames_in_flight"):
+            self._frames_in_flight = {}
+        self._frames_in_flight[int(t)] = (rgb, chunks, mask)
+        for old in [k for k in self._frames_in_flight if k < int(t) - 16]:      # (tickets nobody waited for)
+            del self._frames_in_flight[old]
+        return int(t)
+
+    def decode_frame_wait(self, ticket):
+        """Blocks until the frame is complete. Returns (good_bytes, chunks (12,625) uint8, mask int) like decode_frame."""
+        rc = self._lib.cimbar_hip_decode_frame_wait(self._ctx, int(ticket))
+        self._check(rc, "cimbar_hip_decode_frame_wait")
+        _rgb, chunks, mask = self._frames_in_flight.pop(int(ticket))
         return rc, chunks, mask.value
 
     def decode_batch(self, frames, should_preprocess=False, color_correction=2):

@@ -159,6 +159,26 @@ public:
 		return detail::with_mat(img, [&](const auto& m) { return decode_fountain_mat(m, ostream, should_preprocess, color_correction); });
 	}
 
+	// The same with ONE frame in flight, for cimbar.cpp:124-171's loop (the next image is read / extracted while this one decodes): the call starts
+	// this frame on the device (cimbar_hip_decode_frame_async) and delivers -- to the SAME sink, in frame order -- the chunks of the frame started by
+	// the call before it, returning THAT frame's byte count (0 for the very first call). `flush(sink)` after the loop delivers the last frame.
+	// The image may be reused or freed as soon as the call returns unless it lies in page-locked memory, which must stay until the next call / flush.
+	// Chunk order at the sink, the colour-correction carry-over and the sum of the return values are those of decode_fountain.
+	template <typename MAT, typename FOUNTAINSTREAM>
+	unsigned decode_fountain_overlapped(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess = false, int color_correction = 2)
+	{
+		return detail::with_mat(img, [&](const auto& m) { return decode_fountain_overlapped_mat(m, ostream, should_preprocess, color_correction); });
+	}
+	template <typename FOUNTAINSTREAM>
+	unsigned flush(FOUNTAINSTREAM& ostream)
+	{
+		if (!_ctx || _inflight < 0) return 0;
+		const long long t = _inflight;
+		_inflight = -1;
+		const int res = cimbar_hip_decode_frame_wait(_ctx, t);      // writes the slot's chunks and mask
+		return deliver(res, _ov[_inflight_slot].chunks.data(), _ov[_inflight_slot].mask, ostream);
+	}
+
 	// Decoder::decode (Decoder.h:163-169), the `--no-fountain` path (cimbar.cpp:270-272): the frame's 60 Reed-Solomon outputs go to
 	// ostream.write back to back, a block that could not be decoded as 125 zero bytes (what reed_solomon_stream does for an
 	// ofstream / stringstream, reed_solomon_stream.h:96-107). Returns ostream.tellp() like the reference (Decoder.h:116-117).
@@ -192,15 +212,10 @@ public:
 	const std::vector<uint32_t>& last_masks() const { return _masks; }
 
 protected:
-	template <typename MAT, typename FOUNTAINSTREAM>
-	unsigned decode_fountain_mat(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess, int color_correction)
+	// what decode_fountain does with one frame's result: good chunks to the sink in chunk order, the byte count back
+	template <typename FOUNTAINSTREAM>
+	unsigned deliver(int res, const unsigned char* chunks, uint32_t mask, FOUNTAINSTREAM& ostream)
 	{
-		if (!_ctx) return 0;
-		unsigned char* chunks = _frame.data();   // frame_bytes() of the context's mode
-		uint32_t mask = 0;
-		const size_t step = image_step(img);
-		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
-		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
 		_rc = res < 0 ? res : 0;
 		if (res <= 0) return 0;   // CimbReader::_good == false / nothing decoded
 		const unsigned cs = fountain_chunk_size();
@@ -208,6 +223,36 @@ protected:
 			for (unsigned j = 0; j < fountain_chunks_per_frame(); ++j)
 				if (mask & (1u << j)) ostream.write(reinterpret_cast<const char*>(chunks) + (size_t)j * cs, cs);
 		return (unsigned)res;
+	}
+
+	template <typename MAT, typename FOUNTAINSTREAM>
+	unsigned decode_fountain_mat(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess, int color_correction)
+	{
+		if (!_ctx) return 0;
+		(void)flush(ostream);                    // (a frame left in flight by decode_fountain_overlapped goes first: frame order at the sink)
+		unsigned char* chunks = _frame.data();   // frame_bytes() of the context's mode
+		uint32_t mask = 0;
+		const size_t step = image_step(img);
+		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
+		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
+		return deliver(res, chunks, mask, ostream);
+	}
+
+	template <typename MAT, typename FOUNTAINSTREAM>
+	unsigned decode_fountain_overlapped_mat(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess, int color_correction)
+	{
+		if (!_ctx) return 0;
+		// this frame is started first -- its copy and kernels run while the previous frame's chunks go through the sink below -- into the slot
+		// the previous frame does not use (the library writes through the pointers it is given here when the frame is waited for)
+		const int slot = _inflight >= 0 ? 1 - _inflight_slot : 0;
+		_ov[slot].chunks.resize(_frame.size());
+		const long long t = cimbar_hip_decode_frame_async(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, image_step(img),
+		                                                  should_preprocess ? 1 : 0, color_correction, _ov[slot].chunks.data(), &_ov[slot].mask);
+		const unsigned delivered = flush(ostream);
+		if (t < 0) { _rc = (int)t; return delivered; }
+		_inflight = t;
+		_inflight_slot = slot;
+		return delivered;
 	}
 
 	template <typename MAT, typename STREAM>
@@ -250,6 +295,9 @@ protected:
 	int _rc = 0;
 	int32_t _geo[CIMBAR_HIP_GEOMETRY_WORDS] = {};
 	std::vector<unsigned char> _frame;    // one frame's chunk space (cimbar_hip_ctx_bufsize)
+	struct overlap_slot { std::vector<unsigned char> chunks; uint32_t mask = 0; } _ov[2];   // decode_fountain_overlapped: the frame in flight and the one being started
+	long long _inflight = -1;
+	int _inflight_slot = 0;
 	std::vector<unsigned char> _chunks;
 	std::vector<uint32_t> _masks;
 };

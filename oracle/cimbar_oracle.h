@@ -141,6 +141,7 @@ const int32_t* co_last_positions(void); /* 2*CO_CELLS, drifted x,y by cell index
 
 /* ---- the stage in front of the decoder (oracle/cimbar_oracle_extract.c). Parity unpinned at the OpenCV boundary. */
 /* Scanner::preprocess_image(img, fast=true), Scanner.h:148-165: gray -> 3x3|5x5 Gaussian -> Otsu. out: w*h bytes 0/255. Returns the threshold. */
+int co_gray_blur(const uint8_t* rgb, int w, int h, uint8_t* out, int* hist_out);
 int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out);
 /* cv::getPerspectiveTransform as called by Deskewer::deskew, Deskewer.h:36. Row-major 3x3 into m9. */
 int co_perspective_transform(const float* src8, const float* dst8, double* m9);

@@ -39,7 +39,9 @@ static int refl101(int i, int n)
  *                                      [1 2 1]/4, [1 4 6 4 1]/16, fixed point, one rounding, BORDER_REFLECT_101             [assumed-OpenCV]
  *   threshold(0, 255, BINARY | OTSU)   getThreshVal_Otsu_8u on the blurred image, out = v > t ? 255 : 0                 [assumed-OpenCV]
  * out: w*h bytes. Returns the Otsu threshold (or -1 for an unsupported kernel size). */
-int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out)
+/* the first two steps alone -- cvtColor(RGB2GRAY) + GaussianBlur(unit x unit, 0) -- so that the blur can be pinned by itself (tests/test_opencv_pin_vectors.py).
+ * out: w*h bytes; hist (may be NULL): the blurred image's histogram. Returns the kernel size, or -1 for an unsupported one. */
+int co_gray_blur(const uint8_t* rgb, int w, int h, uint8_t* out, int* hist_out)
 {
 	const size_t n = (size_t)w * h;
 	unsigned unit = (unsigned)(w < h ? w : h);
@@ -76,6 +78,16 @@ int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out)
 			hist[v]++;
 		}
 	free(hs); free(gray);
+	if (hist_out) memcpy(hist_out, hist, sizeof hist);
+	return (int)unit;
+}
+
+int co_scan_preprocess(const uint8_t* rgb, int w, int h, uint8_t* out)
+{
+	const size_t n = (size_t)w * h;
+	int hist[256];
+	if (co_gray_blur(rgb, w, h, out, hist) < 0) return -1;
+
 
 	/* thresh.cpp getThreshVal_Otsu_8u, double arithmetic in this order */
 	double mu = 0, scale = 1. / ((double)w * h);

@@ -496,4 +496,41 @@ int ref_cvtcolor(const uint8_t* src, int rows, int cols, int channels, int code,
 	return dst.rows;
 }
 
+// cv::cvtColor(RGB2GRAY) + cv::GaussianBlur(unit x unit, 0) of the cv-shim, the first two calls of Scanner::preprocess_image (Scanner.h:151-160), with the
+// kernel size given by the caller: the blur by itself, for the OpenCV pin vectors (tests/test_opencv_pin_vectors.py)
+int ref_gray_blur(const uint8_t* rgb, int w, int h, int unit, uint8_t* out)
+{
+	cv::Mat img(h, w, CV_8UC3, (void*)rgb), gray;
+	cv::cvtColor(img, gray, cv::COLOR_RGB2GRAY);
+	cv::GaussianBlur(gray, gray, cv::Size(unit, unit), 0);
+	for (int y = 0; y < h; ++y) std::memcpy(out + (size_t)y * w, gray.ptr<uchar>(y), (size_t)w);
+	return unit;
+}
+
+// cv::threshold(BINARY | OTSU) of the cv-shim on a gray image (Scanner::threshold_fast, Scanner.h:126-130, drops the value it returns): out = 0 / 255,
+// returns the threshold
+int ref_otsu_threshold(const uint8_t* gray, int w, int h, uint8_t* out)
+{
+	cv::Mat g(h, w, CV_8UC1, (void*)gray), bin;
+	const double t = cv::threshold(g, bin, 0, 255, cv::THRESH_BINARY | cv::THRESH_OTSU);
+	for (int y = 0; y < h; ++y) std::memcpy(out + (size_t)y * w, bin.ptr<uchar>(y), (size_t)w);
+	return (int)t;
+}
+
+// color_correction::get_moore_penrose_lsm (chromatic_adaptation/color_correction.h:26-39: transpose, invert(DECOMP_SVD), product) on caller-described
+// rows x 3 float matrices, built the way CimbReader::init_ccm builds them (CimbReader.cpp:229-263: push_back of 1x3 rows): the one cv::invert the path makes
+int ref_moore_penrose_lsm(const float* actual, const float* desired, int rows, float* out9)
+{
+	cv::Mat a = cv::Mat::ones(0, 3, CV_32F), d = cv::Mat::ones(0, 3, CV_32F);
+	for (int r = 0; r < rows; ++r) {
+		cv::Mat arow = (cv::Mat_<float>(1, 3) << actual[3 * r], actual[3 * r + 1], actual[3 * r + 2]);
+		cv::Mat drow = (cv::Mat_<float>(1, 3) << desired[3 * r], desired[3 * r + 1], desired[3 * r + 2]);
+		a.push_back(arow);
+		d.push_back(drow);
+	}
+	const cv::Matx<float, 3, 3> m = color_correction::get_moore_penrose_lsm(a, d);
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out9[3 * i + j] = m(i, j);
+	return rows;
+}
+
 }  // extern "C"

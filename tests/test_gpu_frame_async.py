@@ -1,0 +1,162 @@
+"""cimbar_hip_decode_frame_async / _wait: one frame per call with several in flight -- the reference's decode loop (cimbar.cpp:124-171, one
+Decoder::decode_fountain per image) with frame k+1's host-to-device copy beside frame k's kernels. Every frame's chunks, mask, return value and
+the colour-correction carry-over must be what the one-at-a-time loop produces, in the same order."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from libcimbar_amd import HipDecoder
+from libcimbar_amd import decoder as D
+from oracle import pyref
+from tests import frames as F
+
+pytestmark = pytest.mark.gpu
+
+
+def stream_of_frames(synth, n=11, seed=4040):
+    """clean, noisy, tinted (their own matrix matters), wiped (no header: the carried matrix matters), shifted (flood path)"""
+    payload, fr = F.clean_frames(synth, n, seed=seed)
+    out = []
+    for k in range(n):
+        f = fr[k]
+        kind = k % 5
+        if kind == 1:
+            f = F.add_noise(f, 25, k)
+        elif kind == 2:
+            f = (f.astype(np.float32) * np.array([0.85, 1.0, 0.7], np.float32)).astype(np.uint8)
+        elif kind == 3:
+            f = F.blank_region(f, 0, 400, 0, 1024)          # the first symbol chunks (and the header) are gone: colour pass on the carried matrix
+        elif kind == 4:
+            f = F.shift(f, 1, -2)
+        out.append(np.ascontiguousarray(f))
+    return payload, out
+
+
+def one_at_a_time(frames):
+    dec = HipDecoder(0)
+    total, chunks, masks = dec.decode_batch(np.ascontiguousarray(np.stack(frames)))      # frame order == carry order
+    dec.close()
+    return chunks, masks
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_frames_in_flight_equal_the_one_at_a_time_loop(synth, pinned):
+    payload, frames = stream_of_frames(synth)
+    want_chunks, want_masks = one_at_a_time(frames)
+    if pinned:
+        keep = [torch.from_numpy(f).pin_memory() for f in frames]
+        frames = [t.numpy() for t in keep]
+    dec = HipDecoder(0)
+    depth = dec.pipeline_depth
+    tickets, got = [], []
+    for k, f in enumerate(frames):
+        tickets.append(dec.decode_frame_async(f))
+        if len(tickets) - len(got) >= depth:
+            got.append(dec.decode_frame_wait(tickets[len(got)]))
+    while len(got) < len(tickets):
+        got.append(dec.decode_frame_wait(tickets[len(got)]))
+    assert tickets == sorted(tickets) and len(set(tickets)) == len(tickets)
+    for k, (rc, chunks, mask) in enumerate(got):
+        assert mask == want_masks[k], (k, hex(mask), hex(int(want_masks[k])))
+        assert (chunks == want_chunks[k]).all(), k
+        assert rc == 625 * bin(mask).count("1")
+    # and the oracle agrees with the whole stream (carry included)
+    ccm = pyref.CoCcm()
+    for k, f in enumerate(frames):
+        r, wchunks, wmask, ccm = pyref.oracle_decode(f, 0, 2, ccm)
+        assert got[k][2] == wmask and (got[k][1] == wchunks).all() and got[k][0] == r, k
+    dec.close()
+
+
+def test_the_synchronous_call_is_the_same_path(synth):
+    payload, frames = stream_of_frames(synth, 6, seed=77)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dec = HipDecoder(0)
+    for k, f in enumerate(frames):
+        rc, chunks, mask = dec.decode_frame(f)
+        assert mask == want_masks[k] and (chunks == want_chunks[k]).all() and rc == 625 * bin(mask).count("1")
+    dec.close()
+
+
+def test_more_frames_started_than_fit_complete_the_oldest_and_keep_its_result(synth):
+    """starting frame k + depth delivers frame k into the buffers it was started with; its return value is still there for _wait"""
+    payload, frames = stream_of_frames(synth, 8, seed=99)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dec = HipDecoder(0)
+    lib = D.load_library()
+    outs = [(np.zeros((12, 625), np.uint8), ctypes.c_uint32(0xDEAD)) for _ in frames]
+    tickets = []
+    for f, (c, m) in zip(frames, outs):
+        t = lib.cimbar_hip_decode_frame_async(dec._ctx, f.ctypes.data, 1024, 1024, 0, 0, 2, c.ctypes.data, ctypes.byref(m))
+        assert t >= 0
+        tickets.append(t)
+    depth = dec.pipeline_depth
+    for k in range(len(frames) - depth):              # delivered by the calls that needed their slot
+        assert outs[k][1].value == want_masks[k] and (outs[k][0] == want_chunks[k]).all(), k
+    for k, t in enumerate(tickets):
+        rc = lib.cimbar_hip_decode_frame_wait(dec._ctx, t)
+        assert rc == 625 * bin(int(want_masks[k])).count("1"), (k, rc)
+        assert outs[k][1].value == want_masks[k] and (outs[k][0] == want_chunks[k]).all(), k
+    assert lib.cimbar_hip_decode_frame_wait(dec._ctx, tickets[-1] + 5) < 0          # never issued
+    assert lib.cimbar_hip_decode_frame_wait(dec._ctx, -1) < 0
+    dec.close()
+
+
+def test_other_image_sizes_and_strides_inside_a_stream(synth):
+    """a padded image (CimbReader's _gridPadding case), a too-small one and a strided one between ordinary frames: same results and same carry
+    as the synchronous calls in the same order"""
+    payload, frames = stream_of_frames(synth, 5, seed=123)
+    big = np.zeros((1040, 1060, 3), np.uint8)
+    big[8:1032, 8:1032] = frames[1]
+    small = np.zeros((500, 500, 3), np.uint8)
+    strided = np.full((1024, 1024 * 3 + 96), 0x5A, np.uint8)
+    strided[:, :3072] = frames[3].reshape(1024, -1)
+    seq = [frames[0], big, small, frames[2], strided, frames[4]]
+
+    def run(dec, use_async):
+        lib = D.load_library()
+        res, tickets, outs = [], [], []
+        for img in seq:
+            c, m = np.zeros((12, 625), np.uint8), ctypes.c_uint32(0)
+            if img.ndim == 2:
+                args = (img.ctypes.data, 1024, 1024, img.strides[0])
+            else:
+                args = (img.ctypes.data, img.shape[1], img.shape[0], img.strides[0])
+            if use_async:
+                t = lib.cimbar_hip_decode_frame_async(dec._ctx, *args, 0, 2, c.ctypes.data, ctypes.byref(m))
+                assert t >= 0
+                tickets.append(t)
+                outs.append((c, m))
+            else:
+                rc = lib.cimbar_hip_decode_frame(dec._ctx, *args, 0, 2, c.ctypes.data, ctypes.byref(m))
+                res.append((rc, c.copy(), m.value))
+        for t, (c, m) in zip(tickets, outs):
+            rc = lib.cimbar_hip_decode_frame_wait(dec._ctx, t)
+            res.append((rc, c.copy(), m.value))
+        return res
+    a, b = HipDecoder(0), HipDecoder(0)
+    ra, rb = run(a, True), run(b, False)
+    for k, (x, y) in enumerate(zip(ra, rb)):
+        assert x[0] == y[0] and x[2] == y[2] and (x[1] == y[1]).all(), k
+    assert ra[2][0] == 7500 and ra[2][2] == 0xFFF and not ra[2][1].any()          # the too-small image: the reference's all-zero chunks
+    a.close()
+    b.close()
+
+
+def test_batches_and_frames_interleave_on_one_context(synth):
+    """a pipelined / ordinary batch between frames in flight: every entry point waits for what it must"""
+    payload, frames = stream_of_frames(synth, 6, seed=321)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dec = HipDecoder(0)
+    t0 = dec.decode_frame_async(frames[0])
+    t1 = dec.decode_frame_async(frames[1])
+    total, chunks, masks = dec.decode_batch(np.ascontiguousarray(np.stack(frames[2:4])))        # carries on from frame 1's matrix
+    t4 = dec.decode_frame_async(frames[4])
+    t5 = dec.decode_frame_async(frames[5])
+    r = [dec.decode_frame_wait(t) for t in (t0, t1)] + [(None, chunks[0], int(masks[0])), (None, chunks[1], int(masks[1]))] + \
+        [dec.decode_frame_wait(t) for t in (t4, t5)]
+    for k in range(6):
+        assert r[k][2] == want_masks[k] and (r[k][1] == want_chunks[k]).all(), k
+    dec.close()

@@ -3,7 +3,10 @@ boxes of the pool, and there is no network to install it from, so this module no
 the path (cvtColor RGB2GRAY, adaptiveThreshold 5 / 7, filter2D with CimbReader's sharpen kernel, GaussianBlur 3 / 5 / 9, threshold OTSU,
 getPerspectiveTransform + warpPerspective INTER_LINEAR) are compared bit for bit with the oracle's restatement of them on synthetic frames
 and captures. A maintainer with OpenCV >= 4.5 runs `pytest tests/test_opencv_pin.py` and turns every [assumed-OpenCV] of the sources into a
-checked statement (or finds the first counter-example)."""
+checked statement (or finds the first counter-example).
+
+The portable form of the same pin -- a JSON written once on any machine with cv2 and checked here without it -- is tools/opencv_pin_vectors.py +
+tests/test_opencv_pin_vectors.py."""
 import numpy as np
 import pytest
 

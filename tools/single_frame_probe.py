@@ -49,3 +49,19 @@ e0.record()
 for q in range(64): dec.decode_batch_device(d.data_ptr(), 1, ch.data_ptr(), ms.data_ptr(), False, 2, st)
 e1.record(); torch.cuda.synchronize()
 print("device-resident n=1, 64 calls back to back, GPU time per call:", round(e0.elapsed_time(e1) / 64, 4), "ms")
+# ---- frames in flight
+dec.enable_timing(False)
+depth = dec.pipeline_depth
+for rep in range(3):
+    tk = []
+    t0 = time.perf_counter()
+    for q in range(256):
+        tk.append(dec.decode_frame_async(frames[q % 16]))
+        if len(tk) >= depth: dec.decode_frame_wait(tk.pop(0))
+    while tk: dec.decode_frame_wait(tk.pop(0))
+    dt = (time.perf_counter() - t0) / 256
+    print("frames in flight (pinned):", round(dt * 1e3, 4), "ms per frame =", round(1 / dt), "frames/s")
+t0 = time.perf_counter()
+for q in range(64): tk = dec.decode_frame_async(frames[q % 16])
+print("host time of one async call (no wait, ring full -> includes completing the oldest):", round((time.perf_counter() - t0) / 64 * 1e3, 4), "ms")
+for q in range(4): dec.decode_frame_wait(tk - q) if q < depth else None
