@@ -303,7 +303,7 @@ def extras(dec, dev, stream, n, outs, steps):
         # ---- the same loop with frames in flight (cimbar_hip_decode_frame_async / _wait): frame k+1's H2D copy beside frame k's kernels, chunks
         # taken in order -- what the adapter's Decoder::decode_fountain_overlapped does under cimbar.cpp:124-171's loop
         try:
-            k, depth = 256, dec.pipeline_depth
+            k, depth = 512, dec.pipeline_depth          # (a repetition must outlast the clock ramp-up after the synchronous loop above: ~20 ms)
             tickets = [dec.decode_frame_async(hv[q]) for q in range(depth)]
             for t in tickets:
                 dec.decode_frame_wait(t)
