@@ -160,3 +160,24 @@ def test_batches_and_frames_interleave_on_one_context(synth):
     for k in range(6):
         assert r[k][2] == want_masks[k] and (r[k][1] == want_chunks[k]).all(), k
     dec.close()
+
+
+@pytest.mark.parametrize("mode", [67, 66, 4, 8])
+def test_frames_in_flight_in_every_mode(mode):
+    """the other geometries (1024x720, 736x637) and the legacy single-stream modes through the same entry points: equal to the batch call"""
+    from libcimbar_amd import framegen
+    synth_m = framegen.FrameSynth("cpu", mode)
+    payload = framegen.synth_payload(7, seed=900 + mode, mode=mode)
+    frames = synth_m.frames_from_payload(payload).numpy()
+    frames = [np.ascontiguousarray(F.add_noise(f, 12, k) if k % 2 else f) for k, f in enumerate(frames)]
+    ref = HipDecoder(0, mode)
+    total, want_chunks, want_masks = ref.decode_batch(np.ascontiguousarray(np.stack(frames)))
+    ref.close()
+    dec = HipDecoder(0, mode)
+    tickets = [dec.decode_frame_async(f) for f in frames]          # more than fit: the oldest are completed by the calls that need their slot
+    for k, t in enumerate(tickets):
+        rc, chunks, mask = dec.decode_frame_wait(t)
+        assert mask == want_masks[k] and (chunks == want_chunks[k]).all(), (mode, k)
+        assert rc == dec.geo.CHUNK * bin(mask).count("1")
+    assert (np.stack([want_chunks[k].reshape(-1) for k in range(0, 7, 2)]) == payload.numpy()[0::2]).all()      # the clean ones decode to what was encoded
+    dec.close()
