@@ -13,8 +13,10 @@ dev = torch.device("cuda", 0)
 dec = HipDecoder(0)
 st = torch.cuda.current_stream(dev)
 out = {}
-for kind in ("config5", "shift"):
-    for n in (256, 1024):
+KINDS = tuple(os.environ.get("PROF_KINDS", "config5,shift").split(","))
+SIZES = tuple(int(x) for x in os.environ.get("PROF_NS", "256,1024").split(","))      # (2048 and up: the dense instance, eight frames per CU)
+for kind in KINDS:
+    for n in SIZES:
         payload = framegen.synth_payload(n, seed=777, device=dev)
         frames = torch.empty((n, modeb.IMG, modeb.IMG, 3), dtype=torch.uint8, device=dev)
         dec.encode_batch_device(payload.data_ptr(), n, frames.data_ptr(), st.cuda_stream)

@@ -38,7 +38,7 @@ for path in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"
         for row in csv.DictReader(f):
             k = row.get("Kernel_Name", "")
             name = None
-            for cand in ("k_flood3", "k_flood2", "k_flood_wave", "k_warp_matrices", "k_warp", "k_scan_gray_blur_rows", "k_scan_gray_blur", "k_scan_otsu", "k_scan_stage_rows", "k_scan_stage1",
+            for cand in ("k_flood3", "k_flood_wave", "k_warp_matrices", "k_warp", "k_scan_gray_blur_rows", "k_scan_gray_blur", "k_scan_otsu", "k_scan_stage_rows", "k_scan_stage1",
                          "k_scan_confirm", "k_scan_select", "k_scan_final", "k_scan_offsets", "k_threshold", "k_symbols", "k_colors", "k_rs", "k_frame_mid", "k_frame_end"):
                 if cand in k:
                     name = cand
