@@ -1,8 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + PMC passes of bench.py. Usage: tools/gpu_profile.sh <tag>
 # Counters are collected in their own runs (no --sys-trace etc. together with --pmc).
+# K1=tall tools/gpu_profile.sh <tag>: every launch takes the threshold kernel's tall-strip instance (k_threshold<2, false, 7>, what the pipelined loop
+# launches for large batches) instead of the short-strip one a call that runs alone gets -- the --no-pipeline traces then time THAT kernel alone.
 TAG=${1:-run}
 R=$PWD
+if [ -n "$K1" ]; then export CIMBAR_HIP_K1_STRIPS=$K1; fi
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -18,7 +18,8 @@ def ours(name):
 
 
 def short(name):
-    for k in ("k_threshold<2, false>", "k_threshold<3, true>", "k_rs<4>", "k_rs<2>", "k_symbols", "k_flood_wave", "k_flood3", "k_frame_mid", "k_colors",
+    for k in ("k_threshold<2, false, 7>", "k_threshold<2, false, 6>", "k_threshold<2, false, 2>", "k_threshold<2, false, 3>", "k_threshold<3, true, 2>", "k_threshold<3, true, 3>",
+              "k_threshold<2, false>", "k_threshold<3, true>", "k_rs<4>", "k_rs<2>", "k_symbols", "k_flood_wave", "k_flood3", "k_frame_mid", "k_colors",
               "k_frame_end", "k_carry_out", "k_count_flagged", "k_plane_bytes", "k_png_inflate4<2048>", "k_png_inflate<8192, true>", "k_png_inflate<8192, false>",
               "k_png_inflate<32768, true>", "k_png_inflate<32768, false>", "k_png_unfilter"):
         if k in name:
