@@ -37,23 +37,25 @@ def test_tall_and_short_strips_give_the_same_everything(mode):
     frames = mixed_frames(mode)
     n = len(frames)
     res = {}
-    for which in ("short", "tall"):
-        dec = decoder_with({"CIMBAR_HIP_K1_STRIPS": which}, mode)
-        total, chunks, masks = dec.decode_batch(frames)
-        res[which] = (total, chunks.copy(), masks.copy(), dec.tap(D.TAP_BITPLANE, n).copy(), dec.tap(D.TAP_SYMBOLS, n).copy(),
-                      dec.tap(D.TAP_COLORS, n).copy(), dec.tap(D.TAP_CCM, n).copy(), dec.tap(D.TAP_DRIFT, n).copy())
-        dec.close()
-    a, b = res["short"], res["tall"]
-    assert a[0] == b[0]
-    for name, x, y in zip(("chunks", "masks", "bit plane", "symbols", "colours", "ccm", "drift"), a[1:], b[1:]):
-        assert x.tobytes() == y.tobytes(), f"mode {mode}: {name} differ between the two strip heights"
-    assert (a[2] != 0).any()
+    for pre in (False, True):           # the plain kernel and the sharpening one: both exist in both strip heights
+        for which in ("short", "tall"):
+            dec = decoder_with({"CIMBAR_HIP_K1_STRIPS": which}, mode)
+            total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
+            res[which] = (total, chunks.copy(), masks.copy(), dec.tap(D.TAP_BITPLANE, n).copy(), dec.tap(D.TAP_SYMBOLS, n).copy(),
+                          dec.tap(D.TAP_COLORS, n).copy(), dec.tap(D.TAP_CCM, n).copy(), dec.tap(D.TAP_DRIFT, n).copy())
+            dec.close()
+        a, b = res["short"], res["tall"]
+        assert a[0] == b[0]
+        for name, x, y in zip(("chunks", "masks", "bit plane", "symbols", "colours", "ccm", "drift"), a[1:], b[1:]):
+            assert x.tobytes() == y.tobytes(), f"mode {mode}, preprocess {pre}: {name} differ between the two strip heights"
+        assert (a[2] != 0).any()
 
 
 def test_tall_strips_against_the_oracle(synth):
     dec = decoder_with({"CIMBAR_HIP_K1_STRIPS": "tall"})
     items = F.distorted_set(synth, seed=91)[:9]
     check_against_oracle(dec, [f for _, f in items], names=[n for n, _ in items])
+    check_against_oracle(dec, [f for _, f in items[:6]], pre=1, names=[n for n, _ in items[:6]])
     dec.close()
 
 
