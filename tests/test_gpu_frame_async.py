@@ -181,3 +181,17 @@ def test_frames_in_flight_in_every_mode(mode):
         assert rc == dec.geo.CHUNK * bin(mask).count("1")
     assert (np.stack([want_chunks[k].reshape(-1) for k in range(0, 7, 2)]) == payload.numpy()[0::2]).all()      # the clean ones decode to what was encoded
     dec.close()
+
+
+def test_destroying_a_context_with_frames_in_flight(synth):
+    """frames started and never waited for: destroy waits for the device before it frees what the kernels write into; a fresh context works afterwards"""
+    payload, frames = stream_of_frames(synth, 4, seed=11)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dec = HipDecoder(0)
+    for f in frames[:3]:
+        dec.decode_frame_async(f)
+    dec.close()
+    dec = HipDecoder(0)
+    rc, chunks, mask = dec.decode_frame(frames[0])
+    assert mask == want_masks[0] and (chunks == want_chunks[0]).all()
+    dec.close()
