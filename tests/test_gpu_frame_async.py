@@ -195,3 +195,66 @@ def test_destroying_a_context_with_frames_in_flight(synth):
     rc, chunks, mask = dec.decode_frame(frames[0])
     assert mask == want_masks[0] and (chunks == want_chunks[0]).all()
     dec.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_interleaving_of_every_entry_point_keeps_frame_order_semantics(synth, seed):
+    """One context, a seeded random sequence of: frames started / waited (in and out of ticket order), synchronous frames, ordinary batches, pipelined
+    batches from device memory. Whatever the interleaving, frame k's chunks, mask and colour-correction carry must be those of decoding the same frames
+    one after the other in submission order (what a single reference thread produces)."""
+    rng = np.random.default_rng(1000 + seed)
+    payload, frames = stream_of_frames(synth, 24, seed=700 + seed)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dev = torch.device("cuda", 0)
+    dec = HipDecoder(0)
+    st = torch.cuda.current_stream(dev)
+    got = {}
+    pending = []          # (ticket, frame index)
+    device_batches = []   # (first index, count, chunks tensor, masks tensor, frames tensor)
+    k = 0
+    while k < len(frames):
+        op = int(rng.integers(0, 5))
+        if op == 0:                                   # start one frame
+            pending.append((dec.decode_frame_async(frames[k]), k))
+            k += 1
+        elif op == 1 and pending:                     # wait for a random pending frame (not necessarily the oldest)
+            t, idx = pending.pop(int(rng.integers(0, len(pending))))
+            rc, c, m = dec.decode_frame_wait(t)
+            got[idx] = (c.copy(), m)
+        elif op == 2:                                 # a synchronous frame
+            rc, c, m = dec.decode_frame(frames[k])
+            got[k] = (c.copy(), m)
+            k += 1
+        elif op == 3:                                 # an ordinary batch of 1-3 frames from host memory
+            n = min(int(rng.integers(1, 4)), len(frames) - k)
+            total, c, m = dec.decode_batch(np.ascontiguousarray(np.stack(frames[k:k + n])))
+            for j in range(n):
+                got[k + j] = (c[j].copy(), int(m[j]))
+            k += n
+        elif op == 4:                                 # a pipelined batch of 1-2 frames from device memory
+            n = min(int(rng.integers(1, 3)), len(frames) - k)
+            fr = torch.from_numpy(np.ascontiguousarray(np.stack(frames[k:k + n]))).to(dev)
+            c = torch.zeros((n, 7500), dtype=torch.uint8, device=dev)
+            m = torch.zeros(n, dtype=torch.int32, device=dev)
+            dec.decode_batch_pipelined(fr.data_ptr(), n, c.data_ptr(), m.data_ptr(), False, 2, st.cuda_stream)
+            device_batches.append((k, n, c, m, fr))
+            k += n
+        # never more tickets outstanding than the library keeps results for
+        while len(pending) > 8:
+            t, idx = pending.pop(0)
+            rc, c, m = dec.decode_frame_wait(t)
+            got[idx] = (c.copy(), m)
+    for t, idx in pending:
+        rc, c, m = dec.decode_frame_wait(t)
+        got[idx] = (c.copy(), m)
+    dec.pipeline_wait(st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    for first, n, c, m, _fr in device_batches:
+        for j in range(n):
+            got[first + j] = (c[j].cpu().numpy().reshape(12, 625), int(m[j].item()) & 0xFFFFFFFF)
+    assert sorted(got) == list(range(len(frames)))
+    for idx in range(len(frames)):
+        c, m = got[idx]
+        assert m == want_masks[idx], (seed, idx, hex(m), hex(int(want_masks[idx])))
+        assert (np.asarray(c).reshape(12, 625) == want_chunks[idx]).all(), (seed, idx)
+    dec.close()
