@@ -548,12 +548,12 @@ def extras(dec, dev, stream, n, outs, steps):
         del sample
         # the same at 1024 captures per batch: the exact flood keeps one (two-wavefront) workgroup per frame busy for ~35 ms whatever the batch,
         # so the per-batch time barely moves and throughput follows the batch size until every CU holds its four frames
-        out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=1, key="config5_extract_1024"))
+        out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=2, key="config5_extract_1024"))
         torch.cuda.empty_cache()
         # the same captures as the camera hands them over (web/recv-worker.js: VideoFrames in NV12): `format` 12 of the reference's C ABI, converted
         # inside the kernels that read the capture -- and host-fed, where the format decides how many bytes cross PCIe
         try:
-            out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=1, key="config5_extract_nv12", fmt=12))
+            out.update(extractbench.run(dec, dev, stream, synth, n=1024, reps=2, key="config5_extract_nv12", fmt=12))
             torch.cuda.empty_cache()
             out.update(extractbench.run_host_fed(dec, dev, stream, n=256))
             torch.cuda.empty_cache()
@@ -563,7 +563,7 @@ def extras(dec, dev, stream, n, outs, steps):
         # library runs the replay's dense instance (eight frames per CU: k_flood3<4095, true>)
         for big in (2048, 4096):
             try:
-                out.update(extractbench.run(dec, dev, stream, synth, n=big, reps=1, key=f"config5_extract_{big}"))
+                out.update(extractbench.run(dec, dev, stream, synth, n=big, reps=2, key=f"config5_extract_{big}"))
             except Exception as e:
                 out[f"config5_extract_{big}"] = {"error": repr(e)}
             torch.cuda.empty_cache()
