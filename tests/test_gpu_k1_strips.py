@@ -6,8 +6,10 @@ import numpy as np
 import pytest
 import torch
 
-from libcimbar_amd import HipDecoder, framegen
+from libcimbar_amd import HipDecoder, framegen, geometry
 from libcimbar_amd import decoder as D
+from oracle import pyref
+from oracle.pyref import P
 from tests import frames as F
 from tests.test_gpu_flood_verify import decoder_with
 from tests.test_gpu_parity import check_against_oracle
@@ -84,3 +86,33 @@ def test_the_pipelined_loop_switches_instance_with_the_batch_size(synth):
         torch.cuda.synchronize(dev)
         assert (plane == dec.tap(D.TAP_BITPLANE, 4)).all()
     dec.close()
+
+
+@pytest.mark.parametrize("strips", ["short", "tall"])
+@pytest.mark.parametrize("MODE", [68, 67, 66])
+def test_bitplane_of_images_that_are_busy_at_their_borders(MODE, strips, monkeypatch):
+    """a frame's margin is one flat colour, so the frames above cannot tell BORDER_REPLICATE (box mean) from BORDER_REFLECT_101 (sharpen filter) from
+    anything else at the image's edges. Noise, a diagonal ramp and single bright / dark edge columns and rows can: both threshold variants, both
+    strip heights, every bit of the plane. (Mode 66's rows end inside the last lane of the threshold pass: four of its twelve pixel slots exist.)"""
+    monkeypatch.setenv("CIMBAR_HIP_K1_STRIPS", strips)
+    GEO = geometry.for_mode(MODE)
+    rng = np.random.default_rng(66 + MODE)
+    h, w = GEO.IMG_H, GEO.IMG_W
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = np.stack([(xx * 3 + yy) & 255, (xx + yy * 5) & 255, (xx * 7 - yy) & 255], -1).astype(np.uint8)
+    cols = rng.integers(0, 256, (h, w, 3), dtype=np.uint8) // 4 + 96
+    cols[:, -1] = 255; cols[:, -2] = 0; cols[:, -3] = 200; cols[:, 0] = 0; cols[:, 1] = 255; cols[0] = 255; cols[1] = 10; cols[-1] = 0; cols[-2] = 250
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8), ramp, cols, rng.integers(0, 2, (h, w, 1), dtype=np.uint8).repeat(3, -1) * 255]
+    O = pyref.oracle_lib(MODE)
+    d = D.HipDecoder(0, MODE)
+    try:
+        for pre in (0, 1):
+            d.decode_batch(np.stack(imgs), should_preprocess=pre)
+            got = d.tap(D.TAP_BITPLANE, len(imgs))
+            for k, im in enumerate(imgs):
+                want = np.zeros(w * h // 8, np.uint8)
+                O.co_threshold_bitplane(P(np.ascontiguousarray(im)), w, h, pre, P(want))
+                bad = np.flatnonzero(got[k] != want)
+                assert bad.size == 0, f"pre={pre} image {k}: {bad.size} bitplane bytes differ, first at row {bad[0] // (w // 8)} byte {bad[0] % (w // 8)}"
+    finally:
+        d.close()
