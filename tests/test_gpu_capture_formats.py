@@ -14,6 +14,7 @@ from oracle.pyref import P
 from tests import capture_formats as CF
 from tests import frames as F
 from tests.test_capture_formats import reference_capture_chain
+from tests.test_gpu_flood_verify import decoder_with
 from tests.test_oracle_vs_ref import CAMERA_CASES
 
 pytestmark = pytest.mark.gpu
@@ -121,3 +122,26 @@ def test_format_argument_edges(hip_decoder):
     for fmt in (0, -7, 3, 5):
         got, thr2 = hip_decoder.scan_preprocess(rgb.reshape(1, -1), size=(64, 48), fmt=fmt)
         assert (got == want).all() and thr2[0] == thr[0]
+
+
+@pytest.mark.parametrize("fmt", [12, 420])
+def test_two_pass_warp_in_several_passes(hip_decoder, synth, oracle, fmt):
+    """4:2:0 captures are converted to RGB once per source pixel ahead of the warp, a scratch allowance's worth of captures at a time: with 16 MB of
+    allowance a batch of 1080p captures (6.2 MB each) goes two per pass with an odd one left -- the same frames as in one pass, as with the
+    conversion inside the warp kernel (CIMBAR_HIP_WARP_TWOPASS=0), and as the oracle's"""
+    _, cams = camera_set(synth, fmt)
+    cams = np.ascontiguousarray(np.concatenate([cams, cams[:3]]))
+    assert len(cams) % 2 == 1 and len(cams) >= 5
+    w, h = 1920, 1080
+    status, corners, frames = hip_decoder.extract_batch(cams, size=(w, h), fmt=fmt)
+    for env in ({"CIMBAR_HIP_WARP_SCRATCH_MB": "16"}, {"CIMBAR_HIP_WARP_TWOPASS": "0"}):
+        d = decoder_with(env)
+        try:
+            s2, c2, f2 = d.extract_batch(cams, size=(w, h), fmt=fmt)
+        finally:
+            d.close()
+        assert (s2 == status).all() and (c2 == corners).all() and (f2 == frames).all(), env
+    want = np.zeros((1024, 1024, 3), np.uint8)
+    c8 = (ctypes.c_float * 8)()
+    assert oracle.co_extract_fmt(P(cams[-1]), w, h, fmt, P(want), c8) == status[-1]
+    assert (frames[-1] == want).all()
