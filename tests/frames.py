@@ -86,3 +86,14 @@ def camera_frame(frame, width=1920, height=1080, quad=((500, 40), (1480, 70), (4
     if blur > 0:
         out = out.filter(ImageFilter.GaussianBlur(blur))
     return np.array(out)
+
+
+def border_images(h, w, seed):
+    """images that are busy at their borders (a frame's margin is one flat colour, so frames cannot tell BORDER_REPLICATE from BORDER_REFLECT_101 from
+    anything else there): noise, a diagonal ramp, noise with single bright / dark edge columns and rows, black-and-white noise"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = np.stack([(xx * 3 + yy) & 255, (xx + yy * 5) & 255, (xx * 7 - yy) & 255], -1).astype(np.uint8)
+    cols = rng.integers(0, 256, (h, w, 3), dtype=np.uint8) // 4 + 96
+    cols[:, -1] = 255; cols[:, -2] = 0; cols[:, -3] = 200; cols[:, 0] = 0; cols[:, 1] = 255; cols[0] = 255; cols[1] = 10; cols[-1] = 0; cols[-2] = 250
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8), ramp, cols, rng.integers(0, 2, (h, w, 1), dtype=np.uint8).repeat(3, -1) * 255]

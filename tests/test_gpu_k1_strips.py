@@ -96,13 +96,8 @@ def test_bitplane_of_images_that_are_busy_at_their_borders(MODE, strips, monkeyp
     strip heights, every bit of the plane. (Mode 66's rows end inside the last lane of the threshold pass: four of its twelve pixel slots exist.)"""
     monkeypatch.setenv("CIMBAR_HIP_K1_STRIPS", strips)
     GEO = geometry.for_mode(MODE)
-    rng = np.random.default_rng(66 + MODE)
     h, w = GEO.IMG_H, GEO.IMG_W
-    yy, xx = np.mgrid[0:h, 0:w]
-    ramp = np.stack([(xx * 3 + yy) & 255, (xx + yy * 5) & 255, (xx * 7 - yy) & 255], -1).astype(np.uint8)
-    cols = rng.integers(0, 256, (h, w, 3), dtype=np.uint8) // 4 + 96
-    cols[:, -1] = 255; cols[:, -2] = 0; cols[:, -3] = 200; cols[:, 0] = 0; cols[:, 1] = 255; cols[0] = 255; cols[1] = 10; cols[-1] = 0; cols[-2] = 250
-    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8), ramp, cols, rng.integers(0, 2, (h, w, 1), dtype=np.uint8).repeat(3, -1) * 255]
+    imgs = F.border_images(h, w, 66 + MODE)
     O = pyref.oracle_lib(MODE)
     d = D.HipDecoder(0, MODE)
     try:

@@ -103,6 +103,22 @@ def test_oracle_matches_the_reference_build(ref, MODE, synth67, pre, cc):
             assert (vis == vis2).all(), nm
 
 
+@pytest.mark.parametrize("pre", [0, 1])
+def test_threshold_at_busy_borders_matches_the_reference_build(ref, MODE, pre):
+    """images whose borders are not flat (tests/frames.py border_images): the bit plane of the reference build (CimbReader's preprocessSymbolGrid on the
+    cv-shim) == the oracle's, in this mode's frame size -- where BORDER_REPLICATE / BORDER_REFLECT_101 decide bits"""
+    O = pyref.oracle_lib(MODE)
+    g = geometry.for_mode(MODE)
+    with pyref.ref_mode(MODE):
+        for k, img in enumerate(F.border_images(g.IMG_H, g.IMG_W, 66 + MODE)):
+            img = np.ascontiguousarray(img)
+            b1, vis = np.zeros(g.IMG_W * g.IMG_H // 8, np.uint8), np.zeros((g.NCELLS, 4), np.int32)
+            assert ref.ref_symbol_pass(P(img), g.IMG_W, g.IMG_H, pre, P(b1), P(vis)) == g.NCELLS
+            b2 = np.zeros(g.IMG_W * g.IMG_H // 8, np.uint8)
+            O.co_threshold_bitplane(P(img), g.IMG_W, g.IMG_H, pre, P(b2))
+            assert (b1 == b2).all(), f"image {k}: {(b1 != b2).sum()} bitplane bytes differ"
+
+
 def test_extract_stage_matches_the_reference_build(ref, MODE, synth67):
     """Extractor::extract with the mode's own target size (Extractor.cpp:6-13, Deskewer.h:26-40) on a 1080p capture"""
     g = geometry.for_mode(MODE)

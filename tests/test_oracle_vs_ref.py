@@ -78,6 +78,19 @@ def test_stages_on_distorted_frames(ref, oracle, synth, pre):
         assert (v1 == v2).all(), name
 
 
+@pytest.mark.parametrize("pre", [0, 1])
+def test_threshold_at_busy_borders(ref, oracle, pre):
+    """the same on images whose borders are not flat (tests/frames.py border_images): where the box mean's BORDER_REPLICATE and the sharpen filter's
+    BORDER_REFLECT_101 decide bits. (The GPU kernels are held to the oracle on these images in tests/test_gpu_k1_strips.py.)"""
+    for k, img in enumerate(F.border_images(1024, 1024, 66 + 68)):
+        img = np.ascontiguousarray(img)
+        b1, v1 = np.zeros(131072, np.uint8), np.zeros(4 * 12400, np.int32)
+        assert ref.ref_symbol_pass(P(img), 1024, 1024, pre, P(b1), P(v1)) == 12400
+        b2 = np.zeros(131072, np.uint8)
+        oracle.co_threshold_bitplane(P(img), 1024, 1024, pre, P(b2))
+        assert (b1 == b2).all(), f"image {k}: {(b1 != b2).sum()} bitplane bytes differ"
+
+
 @pytest.mark.parametrize("cc", [0, 1, 2])
 def test_whole_decode_with_ccm_carry(ref, synth, cc):
     # one reference thread decoding a sequence == the oracle carrying its co_ccm through the same sequence
