@@ -78,6 +78,25 @@ def measured_traffic(kernel, n, tall=False):
     return None, None
 
 
+def trace_average(kernel, tall=False):
+    """Average duration (us) of `kernel` in the newest committed rocprofv3 kernel trace of this command that holds it (profiles/*_kernel_stats.csv,
+    written by tools/gpu_profile.sh from `rocprofv3 --kernel-trace --stats`): the figure the HIP-event timing in the same line must agree with."""
+    import csv
+    import glob
+    if kernel != "threshold":
+        return None, None
+    want = "k_threshold<2, false, 7>" if tall else "k_threshold<2, false, 2>"
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")) if "pipelined" not in os.path.basename(f)]
+    for path in sorted(files, key=lambda f: os.path.basename(f), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["kernel"] == want:
+                    return round(float(row["avg_ns"]) / 1e3, 2), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
 def usable_cpus():
     """CPUs this process may really use: the scheduler affinity, cut down to the container's CPU quota where there is one (cgroup v2 cpu.max).
     The GPU boxes of the pool report 256 hardware threads and run under a 16-CPU quota: threads beyond the quota only get throttled."""
@@ -147,7 +166,7 @@ def cpu_baseline(frames_host, gpu_chunks, budget_s=15.0):
             "opencv": "cv-shim (scalar)" if kind == "reference" else "none (C port)",
             "sample": f"{sum(done)} decodes of {len(frames_host)} bench frames, {threads} threads x 1 Decoder, {dt:.1f} s wall",
             "single_thread_frames_per_s": round(1.0 / per_frame, 1), "wall_s": round(dt, 2),
-            "payload_sha_match": sha_cpu == sha_gpu, "payload_sha256": sha_cpu}
+            "payload_sha_match": sha_cpu == sha_gpu, "payload_sha256": sha_cpu, "payload_frames_compared": len(frames_host)}
 
 
 def cpu_baseline_config5(sample, budget_s=10.0):
@@ -704,10 +723,18 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one ordinary call per step instead of the pipelined entry point (kernels of different steps never overlap: "
                          "what tools/gpu_profile.sh uses so that every traced dispatch is one kernel running alone)")
+    ap.add_argument("--probe-run", action="store_true",
+                    help="timing experiment with a probe build of the library (-DCIMBAR_PROBES, CIMBAR_HIP_LIB=libcimbar_amd/variants/libcimbar_hip_probes.so, "
+                         "tools/skip_probe.sh): prints the timing fields only -- no metric / value, such a line is not a result")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test, touches no GPU: start the --gpus ranks exactly as a measurement would, rendezvous them over gloo on "
                          "127.0.0.1, and print one JSON line with every rank's RANK / LOCAL_RANK / WORLD_SIZE")
     args = ap.parse_args()
+    if os.environ.get("CIMBAR_HIP_DEBUG_SKIP", "0") not in ("", "0") and not args.probe_run:
+        # (the product library ignores the variable -- the switch only exists in a -DCIMBAR_PROBES build -- but a line printed while it is set would
+        # invite exactly the doubt it is easiest to avoid)
+        raise SystemExit("bench: CIMBAR_HIP_DEBUG_SKIP is set (chain kernels dropped, results wrong on purpose): no measurement line is printed "
+                         "under it; timing experiments go through --probe-run (tools/skip_probe.sh)")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` (the shape of the driver's N = 1 command) IS the N-rank job: one process per GPU, started here
@@ -760,7 +787,7 @@ def main():
     outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev))
             for _ in range(NB)]
     gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8, device=dev),
-                 torch.zeros((world * n,), dtype=torch.int32, device=dev)) if (world > 1 and rank == 0) else None for _ in range(NB)]
+                 torch.zeros((world * n,), dtype=torch.int32, device=dev)) if rank == 0 else None for _ in range(NB)]
     stream = torch.cuda.current_stream(dev)
     which = [0] * NB          # input batch last decoded into output set b
 
@@ -796,7 +823,16 @@ def main():
             if not args.allow_fallback:
                 raise SystemExit(f"bench: cimbar_hip_gather_chunks could not be set up on every rank ({exchange_name}); "
                                  "pass --allow-fallback to time torch.distributed.gather instead")
-    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered, dst=0, gather=exchange)
+    if world == 1 and not args.no_pipeline and os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE", "1") != "0":
+        # N = 1: the steps still go through the library's exchange, with a communicator of ONE rank (ncclGather is then a 7.7 MB copy on the device,
+        # a few microseconds per step on the exchange's own stream): the line the driver records shows librccl bound and ncclGather issued inside the
+        # timed loop (config.exchange_ranks = what ncclCommCount says). If RCCL cannot be loaded the line says so and the steps run without it.
+        try:
+            exchange = multigpu.LibraryGather(dec, dev)
+            exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library; one-rank communicator)"
+        except Exception as e:
+            exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {e!r})"
+    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered if exchange is not None or world > 1 else None, dst=0, gather=exchange)
     step, drain = pipe.step, pipe.drain
 
     def barrier():
@@ -832,11 +868,11 @@ def main():
     ok = True
     for b, (chunks, masks) in enumerate(outs[:min(NB, pipe.steps)]):
         ok = ok and bool((masks == 0xFFF).all().item()) and bool((chunks == payloads[which[b]]).all().item())
-    if world > 1 and rank == 0:
+    if pipe.exchanging and rank == 0:
         last_in = (pipe.steps - 1) % R
         ok = ok and all_chunks.shape[0] == world * n and bool((all_chunks[:n] == payloads[last_in]).all().item()) \
             and bool((all_masks == 0xFFF).all().item())
-    if not ok and os.environ.get("CIMBAR_HIP_DEBUG_SKIP", "0") in ("", "0"):   # (the debug mask drops kernels on purpose: timing experiments, tools/skip_probe.sh)
+    if not ok and not args.probe_run:
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
     line = None
@@ -866,6 +902,7 @@ def main():
                     os.environ["CIMBAR_HIP_K1_STRIPS"] = prev_env
         achieved = ALGO_BYTES_PER_FRAME * n / (dom_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom, n, tall=tall_used)
+        trace_us, trace_src = trace_average(dom, tall=tall_used)
         line = {
             "metric": "decoded cimbar frames/s (1024x1024 mode-B)", "value": round(frames_per_s, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -876,7 +913,8 @@ def main():
                        "input": f"{R} distinct synthetic batches decoded in rotation (no step is fed from L2 / Infinity Cache)",
                        "frames_per_gpu_per_step": n, "distinct_input_batches": R,
                        "exchange": exchange_name,
-                       "exchange_ranks": getattr(exchange, "nranks", None),          # ncclCommCount of the library's communicator (None at N = 1: no exchange)
+                       "exchange_ranks": getattr(exchange, "nranks", None),          # ncclCommCount of the library's communicator (None: no exchange ran)
+                       "exchanges_in_timed_run": pipe.gathers,
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
                                       ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom + (" (k_threshold<2, false, 7>: the tall-strip instance the timed loop launches, timed as a launch of its own)" if tall_used else ""),
@@ -885,6 +923,8 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": ALGO_BYTES_PER_FRAME * n,
                          "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
+                         # the same kernel's average duration in the committed rocprofv3 kernel trace (another box of the pool, another day: boxes differ by 5-10 %)
+                         "kernel_avg_us": round(dom_ms * 1e3, 2), "kernel_avg_us_trace": trace_us, "kernel_avg_us_trace_source": trace_src,
                          "whole_path_frac": round(frames_per_s / world * ALGO_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stage_acc.items()},
         }
@@ -894,7 +934,7 @@ def main():
             line["no_pipeline"] = {"ms_per_step": round(ms_u, 4), "frames_per_s": round(n / ms_u * 1e3, 1),
                                    "whole_path_frac": round(n / ms_u * 1e3 * ALGO_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 5)}
         if not args.no_cpu_baseline:
-            k = min(n, 64)
+            k = n          # every frame of the batch (round 5 compared 64 of them): ~6 s of one host thread at 1 024 frames
             chunks, masks = outs[0]
             dec.reset_ccm()
             dec.decode_batch_device(inputs[0].data_ptr(), k, chunks.data_ptr(), masks.data_ptr(), False, 2, stream.cuda_stream)
@@ -906,12 +946,16 @@ def main():
             inputs[1:] = []
             torch.cuda.empty_cache()
             line["extra"] = extras(dec, dev, stream, n, outs, max(20, args.steps // 4))
-    if rank == 0:
+    if rank == 0 and args.probe_run:
+        # a probe line carries timings only: nothing in it can be mistaken for the metric
+        print(json.dumps({"probe_run": True, "debug_skip": os.environ.get("CIMBAR_HIP_DEBUG_SKIP", "0"), "payload_ok": ok,
+                          "ms_per_step": line["ms_per_step"], "stage_ms": line["stage_ms"], "no_pipeline": line.get("no_pipeline")}), flush=True)
+    elif rank == 0:
         line["summary"] = summary(line)          # last key: the driver keeps the tail of the line
         print(json.dumps(line), flush=True)
+    if exchange is not None:
+        exchange.close()
     if world > 1:
-        if exchange is not None:
-            exchange.close()
         dist.destroy_process_group()
 
 

@@ -76,7 +76,19 @@ def build_spilltest(force=False, verbose=False):
     return build_hip(force, verbose, OUT_SPILLTEST, ("CIMBAR_HEAP_LDS=1024", "CIMBAR_SCAN_TINY_LISTS"))
 
 
+def build_probes(force=False, verbose=False):
+    """libcimbar_amd/variants/libcimbar_hip_probes.so: the same source with -DCIMBAR_PROBES -- the only build in which CIMBAR_HIP_DEBUG_SKIP (chain
+    kernels dropped, results wrong on purpose) and the k_rs<.., NOSYND> timing instances exist. Selected with CIMBAR_HIP_LIB=<that file>
+    (tools/skip_probe.sh); never loaded by default, and bench.py refuses to print a line while CIMBAR_HIP_DEBUG_SKIP is set."""
+    d = os.path.join(HERE, "variants")
+    os.makedirs(d, exist_ok=True)
+    return build_hip(force, verbose, os.path.join(d, "libcimbar_hip_probes.so"), ("CIMBAR_PROBES",))
+
+
 if __name__ == "__main__":
+    if "--probes" in sys.argv:
+        print(build_probes(force="--force" in sys.argv, verbose=True))
+        sys.exit(0)
     print(build_hip(force="--force" in sys.argv, verbose=True))
     print(build_spilltest(force="--force" in sys.argv, verbose=True))
     print(build_ingest(force="--force" in sys.argv, verbose=True))

@@ -63,7 +63,10 @@ class LibraryGather:
 
     def __init__(self, dec, dev, group=None):
         self.dec, self.dev, self.group = dec, dev, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # (a job of one process needs no rendezvous: the communicator then has one rank and ncclGather is a copy on the device -- bench.py's N = 1 line
+        # runs its steps through it so that the record the driver takes shows the library's RCCL path loaded and issued inside the timed loop)
+        solo = not dist.is_initialized()
+        self.world, self.rank = (1, 0) if solo else (dist.get_world_size(group), dist.get_rank(group))
         from . import decoder as _d
         box = [None]
         if self.rank == 0:
@@ -71,7 +74,8 @@ class LibraryGather:
                 box[0] = _d.comm_unique_id()
             except Exception as e:          # (no RCCL for the library to bind: every rank must learn that, or the others wait in the broadcast forever)
                 box[0] = e
-        dist.broadcast_object_list(box, src=0, group=group)
+        if not solo:
+            dist.broadcast_object_list(box, src=0, group=group)
         if isinstance(box[0], Exception):
             raise RuntimeError(f"rank 0 could not create a communicator id: {box[0]!r}")
         self.comm = dec.comm_init_rank(box[0], self.world, self.rank)
@@ -127,6 +131,7 @@ class StepPipeline:
         self.gathered = gathered if gathered is not None else [None] * self.nbuf
         self.dst, self.group = dst, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchanging = self.world > 1 or gather is not None     # (an explicit exchange is issued at any job size, one rank included)
         self.pending = [[] for _ in range(self.nbuf)]
         self.fresh = [False] * self.nbuf
         self.steps = 0
@@ -152,7 +157,7 @@ class StepPipeline:
         self.pending[b] = []
         self.issue(b, k)
         self.fresh[b] = True
-        if self.world > 1 and k >= self.depth - 1:
+        if self.exchanging and k >= self.depth - 1:
             self.ready(self.depth - 1)                     # step k-depth+1 is complete from here on in stream order
             self._gather((k - (self.depth - 1)) % self.nbuf)
         return self.outs[b]
@@ -160,7 +165,7 @@ class StepPipeline:
     def drain(self):
         """everything issued so far is complete (and gathered) once the current stream has reached this point"""
         self.ready(0)
-        if self.world > 1:
+        if self.exchanging:
             for j in range(max(0, self.steps - self.nbuf), self.steps):
                 self._gather(j % self.nbuf)
         for b in range(self.nbuf):

@@ -1,11 +1,24 @@
-"""GPU, BASELINE-sized inputs checked through size-independent properties (the oracle would take minutes here)."""
+"""GPU, BASELINE-sized inputs: size-independent properties (round trips, idempotence, linearity) AND -- round 6 -- every frame of the 1 024-frame
+batches of BASELINE configs[1] / configs[2] against the reference build's own Decoder::decode_fountain (oracle/_ref, /root/reference/src/lib/encoder/
+Decoder.h:171-189) on a thread pool: masks and chunk bytes per frame."""
+import hashlib
+
 import numpy as np
 import pytest
 import torch
 
 from libcimbar_amd import framegen, modeb
+from tests.refbatch import reference_batch
 
 pytestmark = pytest.mark.gpu
+
+
+def _assert_equals_reference(frames, chunks, masks):
+    ref_chunks, ref_masks = reference_batch(frames.cpu().numpy())
+    got_c, got_m = chunks.cpu().numpy(), masks.cpu().numpy().astype(np.uint32)
+    assert (got_m == ref_masks).all()
+    bad = [k for k in range(got_c.shape[0]) if hashlib.sha256(got_c[k].tobytes()).digest() != hashlib.sha256(ref_chunks[k].tobytes()).digest()]
+    assert not bad, f"{len(bad)} frames differ from the reference build, first {bad[:4]}"
 
 
 def _decode(dec, frames):
@@ -32,6 +45,8 @@ def test_config2_1024_clean_frames_roundtrip(hip_decoder):
     chunks2, masks2 = _decode(hip_decoder, frames)
     assert bool((chunks2 == chunks).all()) and bool((masks2 == masks).all())
     assert not hip_decoder.tap(5, 1024).any()
+    # ... and frame by frame what the reference build decodes from the same 1 024 images
+    _assert_equals_reference(frames, chunks, masks)
 
 
 def test_config3_cell_errors_are_all_corrected(hip_decoder):
@@ -50,6 +65,8 @@ def test_config3_cell_errors_are_all_corrected(hip_decoder):
     sym = torch.from_numpy(hip_decoder.tap(1, n).astype(np.int64)).to(dev)
     col = torch.from_numpy(hip_decoder.tap(2, n).astype(np.int64)).to(dev)
     assert bool((col * 16 + sym == tiles).all())   # the per-cell decisions are the substituted tiles: errors really reached RS
+    # ... and frame by frame what the reference build (libcorrect's decoder included) makes of the same 1 024 damaged images
+    _assert_equals_reference(frames, chunks, masks)
 
 
 def test_linearity_of_the_payload_path(hip_decoder):
