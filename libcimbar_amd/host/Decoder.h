@@ -229,13 +229,18 @@ protected:
 	unsigned decode_fountain_mat(const MAT& img, FOUNTAINSTREAM& ostream, bool should_preprocess, int color_correction)
 	{
 		if (!_ctx) return 0;
-		(void)flush(ostream);                    // (a frame left in flight by decode_fountain_overlapped goes first: frame order at the sink)
+		// (a frame left in flight by decode_fountain_overlapped goes first: frame order at the sink. Its byte count is part of what this call returns --
+		// the sum of the return values stays the plain loop's -- and an error it reported is not forgotten over this frame's success)
+		const unsigned flushed = flush(ostream);
+		const int flushed_rc = _rc;
 		unsigned char* chunks = _frame.data();   // frame_bytes() of the context's mode
 		uint32_t mask = 0;
 		const size_t step = image_step(img);
 		int res = cimbar_hip_decode_frame(_ctx, reinterpret_cast<const uint8_t*>(img.data), (unsigned)img.cols, (unsigned)img.rows, step,
 		                                  should_preprocess ? 1 : 0, color_correction, chunks, &mask);
-		return deliver(res, chunks, mask, ostream);
+		const unsigned own = deliver(res, chunks, mask, ostream);
+		if (flushed_rc < 0 && _rc == 0) _rc = flushed_rc;
+		return flushed + own;
 	}
 
 	template <typename MAT, typename FOUNTAINSTREAM>

@@ -258,3 +258,35 @@ def test_random_interleaving_of_every_entry_point_keeps_frame_order_semantics(sy
         assert m == want_masks[idx], (seed, idx, hex(m), hex(int(want_masks[idx])))
         assert (np.asarray(c).reshape(12, 625) == want_chunks[idx]).all(), (seed, idx)
     dec.close()
+
+
+def test_a_pageable_image_may_be_overwritten_as_soon_as_the_call_returns(synth):
+    """include/cimbar_hip.h: a pageable `rgb` may be reused or freed at once -- also when it is a strided view (a cv::Mat ROI), which would otherwise go
+    through hipMemcpy2DAsync with the DMA possibly still pending at return. Dense and strided images, scribbled over right after the call."""
+    payload, frames = stream_of_frames(synth, 6, seed=99)
+    want_chunks, want_masks = one_at_a_time(frames)
+    dec = HipDecoder(0)
+    for strided in (False, True):
+        dec.reset_ccm()
+        tickets, outs = [], []
+        for k, f in enumerate(frames):
+            if strided:
+                wide = np.zeros((1024, 1024 * 3 + 192), np.uint8)          # the image is a window of a wider pageable buffer
+                wide[:, 96:96 + 3072] = f.reshape(1024, 3072)
+                view = wide[:, 96:96 + 3072]
+                ptr, stride, owner = view.ctypes.data, wide.strides[0], wide
+            else:
+                owner = f.copy()
+                ptr, stride = owner.ctypes.data, 0
+            chunks = np.zeros((12, 625), np.uint8)
+            mask = ctypes.c_uint32(0)
+            t = dec._lib.cimbar_hip_decode_frame_async(dec._ctx, ptr, 1024, 1024, stride, 0, 2, chunks.ctypes.data, ctypes.byref(mask))
+            assert t >= 0
+            owner[:] = 0xA5                                                 # the caller's buffer is reused at once
+            tickets.append(int(t))
+            outs.append((chunks, mask))
+        for k, t in enumerate(tickets):
+            rc = dec._lib.cimbar_hip_decode_frame_wait(dec._ctx, t)
+            chunks, mask = outs[k]
+            assert mask.value == want_masks[k] and (chunks == want_chunks[k]).all() and rc == 625 * bin(mask.value).count("1"), (strided, k)
+    dec.close()
