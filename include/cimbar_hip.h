@@ -65,9 +65,12 @@ void cimbar_hip_destroy(cimbar_hip_ctx* ctx);
 /* cimbard_get_bufsize() (cimbar_recv_js.cpp:143-146) = fountain_chunks_per_frame() * fountain_chunk_size() of the ACTIVE configuration. The
  * reference's configuration is a thread_local; here it lives in the context, so the faithful counterpart takes one:
  *   cimbar_hip_ctx_bufsize(ctx) : the chunk space one frame of THIS context needs (7500 / 5148 / 3240 / 7500 / 8750 for modes 68 / 67 / 66 / 4 / 8)
- *   cimbar_hip_bufsize()        : the same for the default configuration (mode B, what a thread that never called Config::update has): 7500 */
+ *   cimbar_hip_bufsize()        : the same for the default configuration (mode B, what a thread that never called Config::update has): 7500
+ *   cimbar_hip_mode_bufsize(m)  : the same for the configuration cimbard_configure_decode(m) selects, without a context or a device (what a
+ *                                 cimbard_get_bufsize() replacement answers before the first frame arrives: libcimbar_recv_hip.so) */
 int cimbar_hip_ctx_bufsize(const cimbar_hip_ctx* ctx);
 int cimbar_hip_bufsize(void);
+int cimbar_hip_mode_bufsize(int mode_val);
 
 /* The grid a context was created for -- the Config:: getters the reference's callers size their buffers with (Config.h:52-165):
  * out = {mode, image_size_x, image_size_y, total_cells, fountain_chunks_per_frame, fountain_chunk_size, RS blocks per frame (symbol + colour),

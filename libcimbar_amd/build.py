@@ -70,6 +70,27 @@ def build_ingest(force=False, verbose=False):
     return INGEST_OUT
 
 
+RECV_SRC = os.path.join(HERE, "host", "cimbar_recv_c.cpp")
+RECV_OUT = os.path.join(HERE, "libcimbar_recv_hip.so")
+RECV_HEADER = os.path.join(os.path.dirname(HERE), "include", "cimbar_recv_hip.h")
+
+
+def build_recv(force=False, verbose=False):
+    """libcimbar_recv_hip.so: the reference's own receive-side C symbols for the decode step (cimbard_configure_decode / _get_bufsize /
+    _scan_extract_decode, cimbar_recv_js.h:16-17,36) over libcimbar_hip.so -- plain C++ (g++), include/cimbar_recv_hip.h."""
+    deps = [RECV_SRC, RECV_HEADER, HEADER]
+    if not force and os.path.exists(RECV_OUT) and os.path.getmtime(RECV_OUT) >= max(os.path.getmtime(p) for p in deps) \
+            and os.path.getmtime(RECV_OUT) >= os.path.getmtime(OUT):
+        return RECV_OUT
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", RECV_OUT + ".tmp", RECV_SRC,
+           f"-L{HERE}", "-lcimbar_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(RECV_OUT + ".tmp", RECV_OUT)
+    return RECV_OUT
+
+
 def build_spilltest(force=False, verbose=False):
     """The test-only variant whose flood heap keeps 1024 slots in LDS (everything deeper goes through the spill path) and whose anchor search keeps
     ONE hit per scan row (so that ordinary captures overflow the fast kernels' lists and take the serial slow path, k_scan_serial)."""
@@ -92,3 +113,4 @@ if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
     print(build_spilltest(force="--force" in sys.argv, verbose=True))
     print(build_ingest(force="--force" in sys.argv, verbose=True))
+    print(build_recv(force="--force" in sys.argv, verbose=True))

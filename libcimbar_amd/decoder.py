@@ -30,7 +30,7 @@ EXPORTS = (
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
     "cimbar_hip_comm_init_rank", "cimbar_hip_comm_info", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
     "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
-    "cimbar_hip_ctx_bufsize", "cimbar_hip_set_ccm",
+    "cimbar_hip_ctx_bufsize", "cimbar_hip_mode_bufsize", "cimbar_hip_set_ccm",
     "cimbar_hip_capture_bytes", "cimbar_hip_scan_preprocess_fmt", "cimbar_hip_deskew_batch_fmt", "cimbar_hip_extract_batch_fmt",
     "cimbar_hip_scan_extract_decode_batch_fmt",
 )
@@ -127,6 +127,8 @@ def load_library(path=None):
     lib.cimbar_hip_get_ccm.restype = i32
     lib.cimbar_hip_set_ccm.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.cimbar_hip_set_ccm.restype = i32
+    lib.cimbar_hip_mode_bufsize.argtypes = [i32]
+    lib.cimbar_hip_mode_bufsize.restype = i32
     lib.cimbar_hip_ctx_bufsize.argtypes = [vp]
     lib.cimbar_hip_ctx_bufsize.restype = i32
     lib.cimbar_hip_tap.argtypes = [vp, i32, vp, sz]

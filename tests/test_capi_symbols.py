@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_functions():
         assert hasattr(lib, name), name
     assert lib.cimbar_hip_bufsize() == 7500
+    assert [lib.cimbar_hip_mode_bufsize(m) for m in (68, 67, 66, 4, 8, 0, 5)] == [7500, 5148, 3240, 7500, 8750, 7500, 7500]
 
 
 def test_create_fails_loudly_without_a_gpu():
