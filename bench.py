@@ -682,7 +682,8 @@ def self_launch(n, argv, check_gpus=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
     print("bench: starting " + " ".join(cmd[1:]), file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env, stdout=sys.stdout).returncode          # (the ranks write their line to THIS process's real stdout: claim_stdout)
 
 
 def launch_check(rank, local_rank, world):
@@ -707,7 +708,17 @@ def launch_check(rank, local_rank, world):
     return 0 if ok else 4
 
 
+def claim_stdout():
+    """The JSON line must be the only thing on stdout: libraries print there too (RCCL's version banner lands in the C runtime's buffer and is flushed
+    at exit, BEHIND the line). File descriptor 1 is pointed at stderr for everything else; Python's sys.stdout keeps the real one."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = real
+
+
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -726,6 +737,9 @@ def main():
     ap.add_argument("--probe-run", action="store_true",
                     help="timing experiment with a probe build of the library (-DCIMBAR_PROBES, CIMBAR_HIP_LIB=libcimbar_amd/variants/libcimbar_hip_probes.so, "
                          "tools/skip_probe.sh): prints the timing fields only -- no metric / value, such a line is not a result")
+    ap.add_argument("--solo-exchange", action="store_true",
+                    help="N = 1 only: run every step's outputs through cimbar_hip_gather_chunks with a one-rank RCCL communicator inside the timed loop "
+                         "(what each rank of an N-GPU job does); off by default, the N = 1 line then checks the exchange once outside the timed region")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test, touches no GPU: start the --gpus ranks exactly as a measurement would, rendezvous them over gloo on "
                          "127.0.0.1, and print one JSON line with every rank's RANK / LOCAL_RANK / WORLD_SIZE")
@@ -823,13 +837,15 @@ def main():
             if not args.allow_fallback:
                 raise SystemExit(f"bench: cimbar_hip_gather_chunks could not be set up on every rank ({exchange_name}); "
                                  "pass --allow-fallback to time torch.distributed.gather instead")
-    if world == 1 and not args.no_pipeline and os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE", "1") != "0":
-        # N = 1: the steps still go through the library's exchange, with a communicator of ONE rank (ncclGather is then a 7.7 MB copy on the device,
-        # a few microseconds per step on the exchange's own stream): the line the driver records shows librccl bound and ncclGather issued inside the
-        # timed loop (config.exchange_ranks = what ncclCommCount says). If RCCL cannot be loaded the line says so and the steps run without it.
+    if world == 1 and not args.no_pipeline and args.solo_exchange:
+        # N = 1 with --solo-exchange: the steps go through the library's exchange with a communicator of ONE rank, exactly as the ranks of an N-GPU job
+        # do. NOT the default: measured on one box (profiles/r06a_*), the one-rank ncclGather per step takes the N = 1 step from 0.728 to 0.853 ms --
+        # RCCL's kernel shares the CUs with the threshold pass -- so the default N = 1 line runs without it and proves the RCCL path with ONE gather
+        # outside the timed region instead (config.exchange_selfcheck below).
         try:
-            exchange = multigpu.LibraryGather(dec, dev)
-            exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library; one-rank communicator)"
+            exchange = multigpu.LibraryGather(dec, dev, copy_only=os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE") == "copy")
+            exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library; one-rank communicator)" if not exchange.copy_only \
+                else "a device-to-device copy in the exchange's place (experiment: the exchange's stream / event structure without RCCL's kernel)"
         except Exception as e:
             exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {e!r})"
     pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered if exchange is not None or world > 1 else None, dst=0, gather=exchange)
@@ -875,6 +891,22 @@ def main():
     if not ok and not args.probe_run:
         raise SystemExit("bench: decoded payload differs from what was encoded -- number would be meaningless")
 
+    # N = 1 without an exchange in the loop: ONE gather of the last step's outputs through the library's RCCL path (a one-rank communicator), outside the
+    # timed region, compared byte for byte -- the record then shows librccl bound and ncclGather issued by the library on this box
+    selfcheck = None
+    if world == 1 and exchange is None and not args.probe_run:
+        try:
+            ex1 = multigpu.LibraryGather(dec, dev)
+            c_in, m_in = outs[(pipe.steps - 1) % NB]
+            c_out, m_out = torch.zeros_like(c_in), torch.zeros_like(m_in)
+            ex1(c_in, m_in, dst=0, out=(c_out, m_out), async_op=False)
+            torch.cuda.synchronize(dev)
+            selfcheck = {"ranks": ex1.nranks, "gathered_equals_decoded": bool((c_out == c_in).all().item()) and bool((m_out == m_in).all().item()),
+                         "what": "one cimbar_hip_gather_chunks (ncclGather over RCCL, one-rank communicator) of the last step's chunks and masks, outside the timed region"}
+            ex1.close()
+        except Exception as e:
+            selfcheck = {"error": repr(e)}
+
     line = None
     if rank == 0:
         frames_per_s = world * n * args.steps / elapsed
@@ -914,7 +946,7 @@ def main():
                        "frames_per_gpu_per_step": n, "distinct_input_batches": R,
                        "exchange": exchange_name,
                        "exchange_ranks": getattr(exchange, "nranks", None),          # ncclCommCount of the library's communicator (None: no exchange ran)
-                       "exchanges_in_timed_run": pipe.gathers,
+                       "exchanges_in_timed_run": pipe.gathers, "exchange_selfcheck": selfcheck,
                        "parallelism": f"frame-sharded x{world}" + (", RCCL gather to rank 0" if world > 1 else "") +
                                       ("" if args.no_pipeline else f"; {D} steps in flight (pipelined entry point)")},
             "roofline": {"bound": "hbm", "kernel": dom + (" (k_threshold<2, false, 7>: the tall-strip instance the timed loop launches, timed as a launch of its own)" if tall_used else ""),

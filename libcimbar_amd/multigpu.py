@@ -61,8 +61,9 @@ class LibraryGather:
     for, so it overlaps the decode steps issued afterwards. torch.distributed only carries the 128-byte communicator id to the ranks
     (rendezvous); no torch collective touches the data path."""
 
-    def __init__(self, dec, dev, group=None):
+    def __init__(self, dec, dev, group=None, copy_only=False):
         self.dec, self.dev, self.group = dec, dev, group
+        self.copy_only = copy_only      # (experiment, one rank only: a plain device copy in ncclGather's place -- the same streams and events without RCCL's kernel)
         # (a job of one process needs no rendezvous: the communicator then has one rank and ncclGather is a copy on the device -- bench.py's N = 1 line
         # runs its steps through it so that the record the driver takes shows the library's RCCL path loaded and issued inside the timed loop)
         solo = not dist.is_initialized()
@@ -94,8 +95,13 @@ class LibraryGather:
         before = torch.cuda.Event()
         before.record(torch.cuda.current_stream(self.dev))
         self.stream.wait_event(before)
-        self.dec.gather_chunks(self.comm, dst, chunks.data_ptr(), masks.data_ptr(), chunks.shape[0],
-                               all_c.data_ptr() if all_c is not None else 0, all_m.data_ptr() if all_m is not None else 0, self.stream.cuda_stream)
+        if self.copy_only and self.world == 1:
+            with torch.cuda.stream(self.stream):
+                all_c.copy_(chunks, non_blocking=True)
+                all_m.copy_(masks, non_blocking=True)
+        else:
+            self.dec.gather_chunks(self.comm, dst, chunks.data_ptr(), masks.data_ptr(), chunks.shape[0],
+                                   all_c.data_ptr() if all_c is not None else 0, all_m.data_ptr() if all_m is not None else 0, self.stream.cuda_stream)
         done = torch.cuda.Event()
         done.record(self.stream)
         work = _EventWork(done)
