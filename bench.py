@@ -791,7 +791,9 @@ def main():
     # still in batch order). A step's outputs are consumed D-1 steps later: with N > 1 the RCCL gather of step k-D+1 is issued right
     # after step k has been enqueued. D output buffer sets (and, on rank 0, D gather destinations).
     D = 1 if args.no_pipeline else dec.pipeline_depth
-    NB = max(D, 2)
+    # output buffer sets: one per step in flight, and two more where an exchange reads them (a set is handed to a new step only when the gather that
+    # last read it is over: with spare sets that wait is never the one the loop is standing on)
+    NB = max(D, 2) + (2 if (world > 1 or args.solo_exchange) else 0)
     # R distinct input batches, decoded in rotation: steps in flight at the same time never read the same frames (two threshold passes
     # walking the same addresses a few frames apart would share lines through L2 / the Infinity Cache, which a real stream cannot)
     R = max(dec.pipeline_depth, 4)          # (12 GB per rotation: nothing survives in the 256 MiB Infinity Cache from one use to the next)
@@ -848,7 +850,12 @@ def main():
                 else "a device-to-device copy in the exchange's place (experiment: the exchange's stream / event structure without RCCL's kernel)"
         except Exception as e:
             exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {e!r})"
-    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered if exchange is not None or world > 1 else None, dst=0, gather=exchange)
+    ready_gather = None
+    if exchange is not None and not args.no_pipeline:
+        def ready_gather(keep_newest):          # the exchange's stream (not the caller's) waits for the steps whose outputs it is about to read
+            dec.pipeline_wait(exchange.stream.cuda_stream, keep_newest=keep_newest)
+    pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered if exchange is not None or world > 1 else None, dst=0, gather=exchange,
+                                 ready_for_gather=ready_gather)
     step, drain = pipe.step, pipe.drain
 
     def barrier():

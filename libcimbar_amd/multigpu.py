@@ -129,8 +129,13 @@ class StepPipeline:
     issue(buf, step) enqueues one decode into outs[buf]; ready(keep_newest) makes the current stream wait for every issued step
     except the `keep_newest` most recent ones. Both are callables so that the CPU test can drive the same logic with gloo."""
 
-    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None, gather=None):
+    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None, gather=None, ready_for_gather=None):
         self.outs, self.depth, self.issue, self.ready = outs, max(1, int(depth)), issue, ready
+        # ready_for_gather(keep_newest): orders the EXCHANGE's own stream behind the issued steps instead of the caller's. Round 6, measured at N = 1 with
+        # a one-rank communicator (profiles/r06b_bench_exchange_*): making the caller's stream wait for step k-depth+1 before every gather -- the stream
+        # the next step's "frames are ready" event is recorded on -- cost the pipelined loop 11 % (0.759 -> 0.840 ms per step), with ncclGather or a plain
+        # device copy in its place alike: the wait, not RCCL's kernel. Falls back to `ready` (the CPU test's callables, torch.distributed's gather).
+        self.ready_for_gather = ready_for_gather
         self.gather_fn = gather if gather is not None else gather_chunks     # e.g. a LibraryGather: the library's own RCCL exchange
         self.nbuf = len(outs)
         assert self.nbuf >= self.depth, "one output buffer set per step in flight"
@@ -164,7 +169,7 @@ class StepPipeline:
         self.issue(b, k)
         self.fresh[b] = True
         if self.exchanging and k >= self.depth - 1:
-            self.ready(self.depth - 1)                     # step k-depth+1 is complete from here on in stream order
+            (self.ready_for_gather or self.ready)(self.depth - 1)     # step k-depth+1 is complete from here on in (the exchange's) stream order
             self._gather((k - (self.depth - 1)) % self.nbuf)
         return self.outs[b]
 

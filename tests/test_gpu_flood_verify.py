@@ -31,9 +31,11 @@ def decoder_with(env, mode=68, lib_path=None):
 
 
 def dense_env(dense):
-    """0: the instance batches of this size take (k_flood3, LDS state) | 1: the dense instance as shipped -- one wavefront per frame (k_flood1) |
-    2: the two-wavefront dense instance (k_flood3<.., true>, CIMBAR_HIP_FLOOD_SINGLE=0)"""
-    return {"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": "1" if dense else "0", "CIMBAR_HIP_FLOOD_SINGLE": "0" if dense == 2 else "1"}
+    """0: the instance batches of this size take (k_flood3, per-cell state in LDS) | 1: the dense instance as shipped (two wavefronts per frame, tagged
+    hand-over without a barrier) | 2: the same with the barrier per step (CIMBAR_HIP_FLOOD_ASYNC=0) | 3: the dense replay on one wavefront per frame
+    (k_flood1, CIMBAR_HIP_FLOOD_SINGLE=1) | 4: as 0 with the barrier"""
+    return {"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": "1" if dense in (1, 2, 3) else "0", "CIMBAR_HIP_FLOOD_SINGLE": "1" if dense == 3 else "0",
+            "CIMBAR_HIP_FLOOD_ASYNC": "0" if dense in (2, 4) else "1"}
 
 
 def distort_group(fr, g, dev):
@@ -118,9 +120,9 @@ def camera_like(synth, n, seed):
     return out
 
 
-@pytest.mark.parametrize("dense", [0, 1, 2])
+@pytest.mark.parametrize("dense", [0, 1, 2, 3, 4])
 def test_exact_replay_kernel_against_the_oracle(synth, dense):
-    """(dense = 1 | 2: the eight-frames-per-CU instances, one wavefront per frame (k_flood1, what ships) | two (k_flood3<.., true>) -- visited bits in LDS, offered priorities in global memory, 4 160-slot LDS heap, so the
+    """(dense: see dense_env -- 1 | 2 | 3 are the eight-frames-per-CU instances -- visited bits in LDS, offered priorities in global memory, 4 160-slot LDS heap, so the
     shifted frames' heaps also cross into the spill area.) k_flood3 (the exact replay; the earlier generations k_flood / k_flood2 it was first checked against are gone) on shifted, noisy,
     rescaled, pure-noise and camera-like frames, every flagged frame through the exact replay, with and without the sharpening threshold:
     symbols, drifted positions, chunks and masks against the oracle's std::priority_queue-order restatement"""
@@ -150,7 +152,7 @@ def test_exact_replay_kernel_against_the_oracle(synth, dense):
     dec.close()
 
 
-@pytest.mark.parametrize("dense", [1, 2])
+@pytest.mark.parametrize("dense", [1, 2, 3])
 def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroups(synth, dense):
     """CIMBAR_HIP_FLOOD_DENSE_GRID=8 with 30 shifted / rescaled / noisy frames: the launch has 8 workgroups, so 22 frames are handed out through the
     global counter pair (FloodScratch::next, zeroed by the host in front of the launch). Twice on the same context (the second launch must start
@@ -187,7 +189,7 @@ def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroup
     dec.close()
 
 
-@pytest.mark.parametrize("dense", [0, 1, 2])
+@pytest.mark.parametrize("dense", [0, 1, 2, 3, 4])
 def test_exact_replay_kernel_with_the_heap_spilling(synth, dense):
     from libcimbar_amd import build as hipbuild
     from tests.test_gpu_flood import check, flood_frames
