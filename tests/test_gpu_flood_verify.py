@@ -30,14 +30,6 @@ def decoder_with(env, mode=68, lib_path=None):
                 os.environ[k] = v
 
 
-def dense_env(dense):
-    """0: the instance batches of this size take (k_flood3, per-cell state in LDS) | 1: the dense instance as shipped (two wavefronts per frame, tagged
-    hand-over without a barrier) | 2: the same with the barrier per step (CIMBAR_HIP_FLOOD_ASYNC=0) | 3: the dense replay on one wavefront per frame
-    (k_flood1, CIMBAR_HIP_FLOOD_SINGLE=1) | 4: as 0 with the barrier"""
-    return {"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": "1" if dense in (1, 2, 3) else "0", "CIMBAR_HIP_FLOOD_SINGLE": "1" if dense == 3 else "0",
-            "CIMBAR_HIP_FLOOD_ASYNC": "0" if dense in (2, 4) else "1"}
-
-
 def distort_group(fr, g, dev):
     """one random recipe applied to a group of device frames (n, h, w, 3) uint8: rigid shift, wipe, noise, tear, rescale, or a sub-pixel
     (bilinear) warp -- and mixes of them"""
@@ -120,9 +112,9 @@ def camera_like(synth, n, seed):
     return out
 
 
-@pytest.mark.parametrize("dense", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("dense", [0, 1])
 def test_exact_replay_kernel_against_the_oracle(synth, dense):
-    """(dense: see dense_env -- 1 | 2 | 3 are the eight-frames-per-CU instances -- visited bits in LDS, offered priorities in global memory, 4 160-slot LDS heap, so the
+    """(dense = 1: the eight-frames-per-CU instance -- visited bits in LDS, offered priorities in global memory, 4 160-slot LDS heap, so the
     shifted frames' heaps also cross into the spill area.) k_flood3 (the exact replay; the earlier generations k_flood / k_flood2 it was first checked against are gone) on shifted, noisy,
     rescaled, pure-noise and camera-like frames, every flagged frame through the exact replay, with and without the sharpening threshold:
     symbols, drifted positions, chunks and masks against the oracle's std::priority_queue-order restatement"""
@@ -135,7 +127,7 @@ def test_exact_replay_kernel_against_the_oracle(synth, dense):
     frames = np.ascontiguousarray(np.stack(frames))
     n = len(frames)
     xy = modeb.cell_positions()
-    dec = decoder_with(dense_env(dense))
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": str(dense)})
     for pre in (0, 1):
         dec.reset_ccm()
         total, chunks, masks = dec.decode_batch(frames, should_preprocess=pre)
@@ -152,8 +144,7 @@ def test_exact_replay_kernel_against_the_oracle(synth, dense):
     dec.close()
 
 
-@pytest.mark.parametrize("dense", [1, 2, 3])
-def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroups(synth, dense):
+def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroups(synth):
     """CIMBAR_HIP_FLOOD_DENSE_GRID=8 with 30 shifted / rescaled / noisy frames: the launch has 8 workgroups, so 22 frames are handed out through the
     global counter pair (FloodScratch::next, zeroed by the host in front of the launch). Twice on the same context (the second launch must start
     from a zero counter again), every frame against the oracle."""
@@ -171,7 +162,7 @@ def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroup
             frames.append(F.rescale(base, int(g.integers(3, 12))))
     frames = np.ascontiguousarray(np.stack(frames))
     n = len(frames)
-    dec = decoder_with(dict(dense_env(dense), CIMBAR_HIP_FLOOD_DENSE_GRID="8"))
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": "1", "CIMBAR_HIP_FLOOD_DENSE_GRID": "8"})
     want = []
     ccm = pyref.CoCcm()
     for k in range(n):
@@ -189,11 +180,11 @@ def test_dense_replay_hands_frames_out_when_there_are_more_frames_than_workgroup
     dec.close()
 
 
-@pytest.mark.parametrize("dense", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("dense", [0, 1])
 def test_exact_replay_kernel_with_the_heap_spilling(synth, dense):
     from libcimbar_amd import build as hipbuild
     from tests.test_gpu_flood import check, flood_frames
-    dec = decoder_with(dense_env(dense), lib_path=hipbuild.OUT_SPILLTEST)
+    dec = decoder_with({"CIMBAR_HIP_FLOOD_WAVE": "0", "CIMBAR_HIP_FLOOD_DENSE": str(dense)}, lib_path=hipbuild.OUT_SPILLTEST)
     frames, names = flood_frames(synth)
     frames = frames + camera_like(synth, 1, seed=608)
     check(dec, frames, names + ["camera-like"])

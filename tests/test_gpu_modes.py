@@ -134,10 +134,9 @@ def test_exact_replay_instances(synth67, MODE):
     import os
     _, frames = F.clean_frames(synth67, 4, seed=33)
     fr = [F.shift(frames[0], 2, 1), F.shift(frames[1], -3, 2), F.add_noise(F.shift(frames[2], 1, -2), 50, 7), F.rescale(frames[3], 6)]
-    # LDS-state instance | dense (two wavefronts, tagged hand-over: what ships) | dense with the barrier per step | dense on one wavefront per frame (k_flood1)
-    for dense, single, asyn in (("0", "0", "1"), ("1", "0", "1"), ("1", "0", "0"), ("1", "1", "1")):
-        old = {k: os.environ.get(k) for k in ("CIMBAR_HIP_FLOOD_WAVE", "CIMBAR_HIP_FLOOD_DENSE", "CIMBAR_HIP_FLOOD_SINGLE", "CIMBAR_HIP_FLOOD_ASYNC")}
-        os.environ.update(CIMBAR_HIP_FLOOD_WAVE="0", CIMBAR_HIP_FLOOD_DENSE=dense, CIMBAR_HIP_FLOOD_SINGLE=single, CIMBAR_HIP_FLOOD_ASYNC=asyn)
+    for dense in ("0", "1"):
+        old = {k: os.environ.get(k) for k in ("CIMBAR_HIP_FLOOD_WAVE", "CIMBAR_HIP_FLOOD_DENSE")}
+        os.environ.update(CIMBAR_HIP_FLOOD_WAVE="0", CIMBAR_HIP_FLOOD_DENSE=dense)
         try:
             dec = D.HipDecoder(0, MODE)
         finally:
