@@ -737,9 +737,15 @@ def main():
     ap.add_argument("--probe-run", action="store_true",
                     help="timing experiment with a probe build of the library (-DCIMBAR_PROBES, CIMBAR_HIP_LIB=libcimbar_amd/variants/libcimbar_hip_probes.so, "
                          "tools/skip_probe.sh): prints the timing fields only -- no metric / value, such a line is not a result")
-    ap.add_argument("--solo-exchange", action="store_true",
-                    help="N = 1 only: run every step's outputs through cimbar_hip_gather_chunks with a one-rank RCCL communicator inside the timed loop "
-                         "(what each rank of an N-GPU job does); off by default, the N = 1 line then checks the exchange once outside the timed region")
+    ap.add_argument("--no-solo-exchange", dest="solo_exchange", action="store_false",
+                    help="N = 1 only: do NOT run every step's outputs through the library's exchange with a one-rank RCCL communicator inside the timed loop "
+                         "(the default does what each rank of an N-GPU job does: +0.4 ... 1.6 % on the step, profiles/r06m_bench_exchange_*); the line then "
+                         "checks the exchange once outside the timed region instead (config.exchange_selfcheck)")
+    ap.add_argument("--solo-exchange", dest="solo_exchange", action="store_true", help="(the default)")
+    ap.set_defaults(solo_exchange=True)
+    ap.add_argument("--exchange-side-stream", action="store_true",
+                    help="issue the exchange on a stream of its own once the step it reads is complete (rounds 3-5) instead of behind the step on the step's own "
+                         "pipeline stream (cimbar_hip_pipeline_gather): for A/B runs")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test, touches no GPU: start the --gpus ranks exactly as a measurement would, rendezvous them over gloo on "
                          "127.0.0.1, and print one JSON line with every rank's RANK / LOCAL_RANK / WORLD_SIZE")
@@ -791,9 +797,8 @@ def main():
     # still in batch order). A step's outputs are consumed D-1 steps later: with N > 1 the RCCL gather of step k-D+1 is issued right
     # after step k has been enqueued. D output buffer sets (and, on rank 0, D gather destinations).
     D = 1 if args.no_pipeline else dec.pipeline_depth
-    # output buffer sets: one per step in flight, and two more where an exchange reads them (a set is handed to a new step only when the gather that
-    # last read it is over: with spare sets that wait is never the one the loop is standing on)
-    NB = max(D, 2) + (2 if (world > 1 or args.solo_exchange) else 0)
+    # output buffer sets: one per step in flight (the exchange of a step rides on the step's own pipeline stream, so a set always meets the same stream)
+    NB = max(D, 2)
     # R distinct input batches, decoded in rotation: steps in flight at the same time never read the same frames (two threshold passes
     # walking the same addresses a few frames apart would share lines through L2 / the Infinity Cache, which a real stream cannot)
     R = max(dec.pipeline_depth, 4)          # (12 GB per rotation: nothing survives in the 256 MiB Infinity Cache from one use to the next)
@@ -840,22 +845,33 @@ def main():
                 raise SystemExit(f"bench: cimbar_hip_gather_chunks could not be set up on every rank ({exchange_name}); "
                                  "pass --allow-fallback to time torch.distributed.gather instead")
     if world == 1 and not args.no_pipeline and args.solo_exchange:
-        # N = 1 with --solo-exchange: the steps go through the library's exchange with a communicator of ONE rank, exactly as the ranks of an N-GPU job
-        # do. NOT the default: measured on one box (profiles/r06a_*), the one-rank ncclGather per step takes the N = 1 step from 0.728 to 0.853 ms --
-        # RCCL's kernel shares the CUs with the threshold pass -- so the default N = 1 line runs without it and proves the RCCL path with ONE gather
-        # outside the timed region instead (config.exchange_selfcheck below).
+        # N = 1: the steps go through the library's exchange with a communicator of ONE rank, exactly as the ranks of an N-GPU job do: the record the driver
+        # takes then shows librccl bound and ncclGather issued inside the timed loop (config.exchange_ranks = what ncclCommCount says). Since the exchange
+        # rides on the step's own pipeline stream (cimbar_hip_pipeline_gather) this costs the step 0.4 ... 1.6 % (profiles/r06m_bench_exchange_*: 0.716 /
+        # 0.719 and 0.722 / 0.733 ms, without / with, alternated); on a stream of its own it cost 10 % (--exchange-side-stream). --no-solo-exchange leaves
+        # it out and checks the RCCL path with ONE gather outside the timed region instead (config.exchange_selfcheck). If RCCL cannot be loaded the line
+        # says so and the steps run without it.
         try:
             exchange = multigpu.LibraryGather(dec, dev, copy_only=os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE") == "copy")
             exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library; one-rank communicator)" if not exchange.copy_only \
                 else "a device-to-device copy in the exchange's place (experiment: the exchange's stream / event structure without RCCL's kernel)"
         except Exception as e:
             exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {e!r})"
+    # The exchange of a step is issued right behind it on the step's own pipeline stream (cimbar_hip_pipeline_gather): no side stream, no events; the
+    # pipeline wait that makes a step's outputs safe to read covers its gathered chunks as well. (--exchange-side-stream: the round-3..5 arrangement --
+    # the gather of step k-D+1 on a stream of the exchange's own once that step is complete -- kept for A/B runs.)
+    inline = None
     ready_gather = None
-    if exchange is not None and not args.no_pipeline:
+    if exchange is not None and not args.no_pipeline and not getattr(exchange, "copy_only", False) and not args.exchange_side_stream:
+        inline = exchange.inline
+    elif exchange is not None and not args.no_pipeline:
         def ready_gather(keep_newest):          # the exchange's stream (not the caller's) waits for the steps whose outputs it is about to read
             dec.pipeline_wait(exchange.stream.cuda_stream, keep_newest=keep_newest)
+    if inline is not None:
+        exchange_name = "cimbar_hip_pipeline_gather (RCCL ncclGather issued by the library behind each step on the step's own pipeline stream" + \
+                        ("; one-rank communicator)" if world == 1 else ")")
     pipe = multigpu.StepPipeline(outs, D, issue, ready, gathered=gathered if exchange is not None or world > 1 else None, dst=0, gather=exchange,
-                                 ready_for_gather=ready_gather)
+                                 ready_for_gather=ready_gather, inline_gather=inline)
     step, drain = pipe.step, pipe.drain
 
     def barrier():

@@ -270,6 +270,12 @@ int cimbar_hip_comm_info(cimbar_hip_comm* comm, int* nranks, int* rank);
 void cimbar_hip_comm_destroy(cimbar_hip_comm* comm);
 int cimbar_hip_gather_chunks(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int root, const uint8_t* chunks, const uint32_t* masks, int n,
                              uint8_t* all_chunks, uint32_t* all_masks, void* hip_stream);
+/* The same exchange for the batch issued LAST through cimbar_hip_decode_batch_pipelined, enqueued on that batch's own pipeline stream right behind its
+ * kernels (chunks / masks = the buffers that call was given): no stream or event of the caller's is involved, and cimbar_hip_pipeline_wait -- which a
+ * consumer of the batch calls anyway -- then also covers all_chunks / all_masks on the root. Every rank calls it after every pipelined batch, in the same
+ * order. This is what bench.py's N > 1 loop issues per step. CIMBAR_HIP_EINVAL if no pipelined batch has been issued on the context. */
+int cimbar_hip_pipeline_gather(cimbar_hip_ctx* ctx, cimbar_hip_comm* comm, int root, const uint8_t* chunks, const uint32_t* masks, int n,
+                               uint8_t* all_chunks, uint32_t* all_masks);
 
 /* ---- PNG decode on the device (what cv::imread does in front of the decoder, cimbar.cpp:132-133) --------------------
  * A batch of PNG images whose zlib streams (the concatenated IDAT payloads) already sit in device memory -> dense RGB8 frames in device

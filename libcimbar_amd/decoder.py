@@ -28,7 +28,7 @@ EXPORTS = (
     "cimbar_hip_decode_batch_pipelined", "cimbar_hip_pipeline_wait", "cimbar_hip_pipeline_depth",
     "cimbar_hip_scan_preprocess", "cimbar_hip_deskew_batch", "cimbar_hip_tile_hashes",
     "cimbar_hip_extract_batch", "cimbar_hip_scan_extract_decode_batch", "cimbar_hip_comm_init_all", "cimbar_hip_comm_unique_id",
-    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_info", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_device", "cimbar_hip_geometry",
+    "cimbar_hip_comm_init_rank", "cimbar_hip_comm_info", "cimbar_hip_comm_destroy", "cimbar_hip_gather_chunks", "cimbar_hip_pipeline_gather", "cimbar_hip_device", "cimbar_hip_geometry",
     "cimbar_hip_png_scratch_bytes", "cimbar_hip_png_decode_batch", "cimbar_hip_png_decode_batch_v",
     "cimbar_hip_ctx_bufsize", "cimbar_hip_mode_bufsize", "cimbar_hip_set_ccm",
     "cimbar_hip_capture_bytes", "cimbar_hip_scan_preprocess_fmt", "cimbar_hip_deskew_batch_fmt", "cimbar_hip_extract_batch_fmt",
@@ -119,6 +119,8 @@ def load_library(path=None):
     lib.cimbar_hip_comm_destroy.restype = None
     lib.cimbar_hip_gather_chunks.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.cimbar_hip_gather_chunks.restype = i32
+    lib.cimbar_hip_pipeline_gather.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.cimbar_hip_pipeline_gather.restype = i32
     lib.cimbar_hip_device.argtypes = [vp]
     lib.cimbar_hip_device.restype = i32
     lib.cimbar_hip_reset_ccm.argtypes = [vp]
@@ -511,6 +513,12 @@ class HipDecoder:
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(uid))
         self._check(self._lib.cimbar_hip_comm_init_rank(buf, int(nranks), int(rank), int(self.device), ctypes.byref(comm)), "cimbar_hip_comm_init_rank")
         return comm
+
+    def pipeline_gather(self, comm, root, chunks_ptr, masks_ptr, n, all_chunks_ptr, all_masks_ptr):
+        """cimbar_hip_pipeline_gather: the exchange of the pipelined batch issued last, on that batch's own stream (pipeline_wait then covers it)."""
+        self._check(self._lib.cimbar_hip_pipeline_gather(self._ctx, comm, int(root), ctypes.c_void_p(chunks_ptr), ctypes.c_void_p(masks_ptr), int(n),
+                                                         ctypes.c_void_p(all_chunks_ptr) if all_chunks_ptr else None,
+                                                         ctypes.c_void_p(all_masks_ptr) if all_masks_ptr else None), "cimbar_hip_pipeline_gather")
 
     def gather_chunks(self, comm, root, chunks_ptr, masks_ptr, n, all_chunks_ptr, all_masks_ptr, stream=None):
         self._check(self._lib.cimbar_hip_gather_chunks(self._ctx, comm, int(root), ctypes.c_void_p(chunks_ptr), ctypes.c_void_p(masks_ptr), int(n),

@@ -110,6 +110,16 @@ class LibraryGather:
             return all_c, all_m
         return all_c, all_m, [work]
 
+    def inline(self, chunks, masks, dst=0, out=None):
+        """cimbar_hip_pipeline_gather: the exchange of the pipelined batch issued LAST (whose outputs `chunks` / `masks` are), enqueued on that batch's own
+        stream -- no side stream, no event: HipDecoder.pipeline_wait covers the gathered buffers like the batch's outputs. Returns (all_chunks, all_masks)."""
+        all_c, all_m = out if (self.rank == dst and out is not None) else (None, None)
+        if self.rank == dst and out is None:
+            raise ValueError("inline exchange: the root passes its receive buffers (one set per output buffer set)")
+        self.dec.pipeline_gather(self.comm, dst, chunks.data_ptr(), masks.data_ptr(), chunks.shape[0],
+                                 all_c.data_ptr() if all_c is not None else 0, all_m.data_ptr() if all_m is not None else 0)
+        return all_c, all_m
+
     def close(self):
         from . import decoder as _d
         if self.comm is not None:
@@ -129,13 +139,19 @@ class StepPipeline:
     issue(buf, step) enqueues one decode into outs[buf]; ready(keep_newest) makes the current stream wait for every issued step
     except the `keep_newest` most recent ones. Both are callables so that the CPU test can drive the same logic with gloo."""
 
-    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None, gather=None, ready_for_gather=None):
+    def __init__(self, outs, depth, issue, ready, gathered=None, dst=0, group=None, gather=None, ready_for_gather=None, inline_gather=None):
         self.outs, self.depth, self.issue, self.ready = outs, max(1, int(depth)), issue, ready
         # ready_for_gather(keep_newest): orders the EXCHANGE's own stream behind the issued steps instead of the caller's. Round 6, measured at N = 1 with
         # a one-rank communicator (profiles/r06b_bench_exchange_*): making the caller's stream wait for step k-depth+1 before every gather -- the stream
         # the next step's "frames are ready" event is recorded on -- cost the pipelined loop 11 % (0.759 -> 0.840 ms per step), with ncclGather or a plain
         # device copy in its place alike: the wait, not RCCL's kernel. Falls back to `ready` (the CPU test's callables, torch.distributed's gather).
         self.ready_for_gather = ready_for_gather
+        # inline_gather(chunks, masks, dst=, out=): the exchange of the step just issued, enqueued behind it on the step's own stream (LibraryGather.inline
+        # -> cimbar_hip_pipeline_gather). Nothing to wait for before or after: stream order does it all, provided a buffer set always returns to the same
+        # pipeline stream (one set per step in flight), which is asserted here.
+        self.inline_gather = inline_gather
+        if inline_gather is not None:
+            assert len(outs) == self.depth, "inline exchange: exactly one output buffer set per step in flight (a set then always rides the same stream)"
         self.gather_fn = gather if gather is not None else gather_chunks     # e.g. a LibraryGather: the library's own RCCL exchange
         self.nbuf = len(outs)
         assert self.nbuf >= self.depth, "one output buffer set per step in flight"
@@ -168,7 +184,12 @@ class StepPipeline:
         self.pending[b] = []
         self.issue(b, k)
         self.fresh[b] = True
-        if self.exchanging and k >= self.depth - 1:
+        if self.inline_gather is not None:
+            chunks, masks = self.outs[b]
+            self.last = self.inline_gather(chunks, masks, dst=self.dst, out=self.gathered[b])
+            self.fresh[b] = False
+            self.gathers += 1
+        elif self.exchanging and k >= self.depth - 1:
             (self.ready_for_gather or self.ready)(self.depth - 1)     # step k-depth+1 is complete from here on in (the exchange's) stream order
             self._gather((k - (self.depth - 1)) % self.nbuf)
         return self.outs[b]
@@ -176,7 +197,7 @@ class StepPipeline:
     def drain(self):
         """everything issued so far is complete (and gathered) once the current stream has reached this point"""
         self.ready(0)
-        if self.exchanging:
+        if self.exchanging and self.inline_gather is None:
             for j in range(max(0, self.steps - self.nbuf), self.steps):
                 self._gather(j % self.nbuf)
         for b in range(self.nbuf):
