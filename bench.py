@@ -64,17 +64,26 @@ def measured_traffic(kernel, n, tall=False):
     if not files:
         return None, None
     # (round 5: the threshold kernel has two instances, short strips <2, false, 2> and tall ones <2, false, 7>; older summaries name it <2, false>)
+    # (the strip heights are build parameters -- -DCIMBAR_K1_TALLROWS_B, K1_CELLROWS --: the tall instance is the `k_threshold<2, false, N>` with the largest N
+    # a summary holds, the short one the smallest; the names below are the default build's and come first)
     keys = {"threshold": ["k_threshold<2, false, 7>"] if tall else ["k_threshold<2, false, 2>", "k_threshold<2, false>"]}.get(kernel)
+    import re
+
+    def by_rows(pmc):
+        rows = sorted((int(m.group(1)), k) for k in pmc for m in [re.fullmatch(r"k_threshold<2, false, (\d+)>", k)] if m)
+        return [rows[-1][1] if tall else rows[0][1]] if rows else []
     key = {"threshold": "k_threshold<2, false>", "symbols": "k_symbols", "rs_symbols": "k_rs<4>", "rs_colors": "k_rs<2>",
            "colors": "k_colors", "frame_mid": "k_frame_mid", "frame_end": "k_frame_end", "flood": "k_flood3"}[kernel]
-    for path in reversed(files):      # the newest summary that holds this kernel's counters (summaries of other commands live there too)
-        try:
-            pmc = json.load(open(path))["pmc"]
-            c = next(pmc[k] for k in (keys or [key]) if k in pmc)
-            per_1024 = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-            return per_1024 * n / 1024.0, os.path.basename(path)
-        except Exception:
-            continue
+    for fallback in (False, True):     # (first the default build's kernel names in any summary, only then "largest / smallest N" of a non-default build's)
+        for path in reversed(files):      # the newest summary that holds this kernel's counters (summaries of other commands live there too)
+            try:
+                pmc = json.load(open(path))["pmc"]
+                names = by_rows(pmc) if (fallback and kernel == "threshold") else (keys or [key])
+                c = next(pmc[k] for k in names if k in pmc)
+                per_1024 = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                return per_1024 * n / 1024.0, os.path.basename(path)
+            except Exception:
+                continue
     return None, None
 
 

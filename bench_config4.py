@@ -243,7 +243,8 @@ def bench(dec, dev, rank, world, args, quiet=False):
         "config": {"workload": f"BASELINE configs[3]: {n_frames}-frame fountain stream of a {data.size}-byte file split over {world} rank(s) in "
                                f"{slab}-frame slabs, gather to rank 0, single wirehair sink fed inside the timed region (slab s feeds the sink "
                                "while slab s+1 decodes; feeding stops when the file is complete). `value` is bounded by the reference sink's sequential wirehair solve "
-                               "on one host thread; `value_without_solve` is the part that scales with GPUs",
+                               "on one host thread; `value_without_solve` subtracts the sink's mean solve time in full -- an UPPER bound for the part that scales with GPUs "
+                               "(the sink is fed while the next slab decodes, so some of that time is already overlapped)",
                    "frames_total": n_frames, "frames_per_rank": per, "exchange": exchange_name,
                    "parallelism": f"frame-sharded x{world}, RCCL gather to rank 0"},
         "stage_s": {k: round(v, 5) for k, v in acc.items()},

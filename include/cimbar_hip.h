@@ -110,13 +110,17 @@ int cimbar_hip_decode_frame(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned wi
  *                     cimbar_hip_pipeline_depth(ctx) frames are in flight; starting one more first completes the oldest (its chunks and mask land
  *                     in the buffers it was started with; its return value stays available to _wait for the next 16 tickets).
  *                     `rgb` in page-locked memory (hipHostMalloc / hipHostRegister) is copied from where it lies and must stay untouched until the
- *                     frame's _wait; pageable memory is copied to the context's page-locked staging before the call returns and may be reused or
- *                     freed at once. `chunks` / `good_mask` are written by _wait (or by the completion described above), never before.
+ *                     frame's _wait; pageable memory has been consumed when the call returns (a dense image through the runtime's own pageable copy, a
+ *                     strided one -- a cv::Mat ROI -- through the context's page-locked staging) and may be reused or freed at once. `chunks` / `good_mask` are written by _wait (or by the completion described above), never before.
  *                     Images of another size than the frame (CimbReader.cpp:107-126's padded / too-small cases) are decoded synchronously behind
  *                     everything in flight and still get a ticket.
  *   cimbar_hip_decode_frame_wait  : blocks until that frame is complete and returns what cimbar_hip_decode_frame would have returned.
  * Frames are decoded in ticket order (the colour-correction matrix carries over from frame to frame exactly as in the synchronous call), so
- * waiting in ticket order hands the chunks to a sink in the order the reference's loop would. cimbar_hip_decode_frame IS _async + _wait. */
+ * waiting in ticket order hands the chunks to a sink in the order the reference's loop would. cimbar_hip_decode_frame IS _async + _wait.
+ * Mixing with the batch entry points on one context: the frame slots ride on the pipeline's streams and scratch sets and are ordered among
+ * themselves and behind cimbar_hip_decode_batch_pipelined; a batch call with DEVICE outputs on a stream of the caller's only enqueues, shares the
+ * carried matrix and the flood scratch with the frame slots and is NOT ordered against them -- synchronise that stream before the next
+ * cimbar_hip_decode_frame_async (a batch call with host outputs has synchronised when it returns). */
 long long cimbar_hip_decode_frame_async(cimbar_hip_ctx* ctx, const uint8_t* rgb, unsigned width, unsigned height, size_t stride,
                                         int should_preprocess, int color_correction, uint8_t* chunks, uint32_t* good_mask);
 int cimbar_hip_decode_frame_wait(cimbar_hip_ctx* ctx, long long ticket);
