@@ -860,12 +860,26 @@ def main():
         # 0.719 and 0.722 / 0.733 ms, without / with, alternated); on a stream of its own it cost 10 % (--exchange-side-stream). --no-solo-exchange leaves
         # it out and checks the RCCL path with ONE gather outside the timed region instead (config.exchange_selfcheck). If RCCL cannot be loaded the line
         # says so and the steps run without it.
-        try:
-            exchange = multigpu.LibraryGather(dec, dev, copy_only=os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE") == "copy")
+        # (set up on a helper thread with a deadline: a communicator that cannot be built -- no usable socket interface for RCCL's bootstrap in some sandbox --
+        # must cost the line its exchange, never the line itself)
+        box = {}
+
+        def setup():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["exchange"] = multigpu.LibraryGather(dec, dev, copy_only=os.environ.get("CIMBAR_BENCH_SOLO_EXCHANGE") == "copy")
+            except Exception as e:
+                box["error"] = e
+        th = threading.Thread(target=setup, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("CIMBAR_BENCH_EXCHANGE_SETUP_S", "120")))
+        if "exchange" in box:
+            exchange = box["exchange"]
             exchange_name = "cimbar_hip_gather_chunks (RCCL ncclGather issued by the library; one-rank communicator)" if not exchange.copy_only \
                 else "a device-to-device copy in the exchange's place (experiment: the exchange's stream / event structure without RCCL's kernel)"
-        except Exception as e:
-            exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {e!r})"
+        else:
+            why = repr(box["error"]) if "error" in box else "ncclCommInitRank did not return within the deadline"
+            exchange, exchange_name = None, f"none (N = 1; the library's RCCL exchange could not be set up: {why})"
     # The exchange of a step is issued right behind it on the step's own pipeline stream (cimbar_hip_pipeline_gather): no side stream, no events; the
     # pipeline wait that makes a step's outputs safe to read covers its gathered chunks as well. (--exchange-side-stream: the round-3..5 arrangement --
     # the gather of step k-D+1 on a stream of the exchange's own once that step is complete -- kept for A/B runs.)
@@ -1010,8 +1024,8 @@ def main():
             inputs[1:] = []
             torch.cuda.empty_cache()
             line["extra"] = extras(dec, dev, stream, n, outs, max(20, args.steps // 4))
-    if world == 1 and exchange is None and not args.probe_run:
-        # (last of all: creating and destroying an RCCL communicator leaves the process with slower host-side event waits -- measured, the
+    if world == 1 and exchange is None and not args.solo_exchange and not args.probe_run:
+        # (--no-solo-exchange; if the in-loop exchange was wanted and could not be set up, config.exchange says why and nothing is tried again. Last of all: creating and destroying an RCCL communicator leaves the process with slower host-side event waits -- measured, the
         # synchronous one-frame call went from 0.149 to 0.649 ms when this ran ahead of the extra rows, profiles/r06k_bench.json)
         line["config"]["exchange_selfcheck"] = exchange_selfcheck()
     if rank == 0 and args.probe_run:
