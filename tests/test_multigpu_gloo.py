@@ -149,3 +149,61 @@ def test_step_pipeline_gathers_every_step_once_and_in_order(tmp_path, depth, nst
     res = tmp_path / "ok"
     mp.spawn(_pipeline_worker, args=(2, _free_port(), depth, nsteps, str(res)), nprocs=2, join=True)
     assert res.read_text() == "ok"
+
+
+def _inline_worker(rank, world, port, depth, nsteps, result_path):
+    """the same loop with the exchange riding on each step (StepPipeline's inline mode: what bench.py --gpus N issues since round 6 through
+    cimbar_hip_pipeline_gather); the stand-in gathers synchronously over gloo, which is what "in the step's own stream order" means on a CPU"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3
+        outs = [(torch.zeros((n, modeb.FRAME_BYTES), dtype=torch.uint8), torch.zeros((n,), dtype=torch.int32)) for _ in range(depth)]
+        gathered = [(torch.zeros((world * n, modeb.FRAME_BYTES), dtype=torch.uint8), torch.zeros((world * n,), dtype=torch.int32))
+                    if rank == 0 else None for _ in range(depth)]
+        issued, waits, calls = [], [], []
+
+        def issue(b, k):
+            outs[b][0].fill_((k * 7 + rank) % 251)
+            outs[b][1].fill_(k * 100 + rank)
+            issued.append((b, k))
+
+        def ready(keep_newest):
+            waits.append(keep_newest)
+
+        def inline(chunks, masks, dst=0, out=None):
+            calls.append(len(issued) - 1)                # issued right behind the step, before the next one
+            return multigpu.gather_chunks(chunks, masks, dst=dst, out=out)
+
+        pipe = multigpu.StepPipeline(outs, depth, issue, ready, gathered=gathered, dst=0, inline_gather=inline)
+        seen = []
+        for k in range(nsteps):
+            pipe.step()
+            if rank == 0:
+                seen.append((pipe.last[0][:, 0].clone(), pipe.last[1].clone()))
+        pipe.drain()
+        assert pipe.gathers == nsteps and calls == list(range(nsteps)), "every step is exchanged exactly once, right behind its issue"
+        assert waits == [0], "no wait is needed before an exchange that rides on its step: only the drain waits"
+        assert [b for b, _ in issued] == [k % depth for k in range(nsteps)], "a buffer set always returns to the same place in the rotation (= the same pipeline stream)"
+        if rank == 0:
+            for s, (c0, m) in enumerate(seen):
+                want_m = torch.tensor([s * 100 + r for r in range(world) for _ in range(n)], dtype=torch.int32)
+                want_c = torch.tensor([(s * 7 + r) % 251 for r in range(world) for _ in range(n)], dtype=torch.uint8)
+                assert (m == want_m).all() and (c0 == want_c).all(), s
+            open(result_path, "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,nsteps", [(3, 10), (2, 5), (4, 3)])
+def test_step_pipeline_inline_exchange_rides_on_every_step(tmp_path, depth, nsteps):
+    res = tmp_path / "ok"
+    mp.spawn(_inline_worker, args=(2, _free_port(), depth, nsteps, str(res)), nprocs=2, join=True)
+    assert res.read_text() == "ok"
+
+
+def test_inline_exchange_wants_one_buffer_set_per_step_in_flight():
+    outs = [(torch.zeros((1, modeb.FRAME_BYTES), dtype=torch.uint8), torch.zeros((1,), dtype=torch.int32)) for _ in range(5)]
+    with pytest.raises(AssertionError):
+        multigpu.StepPipeline(outs, 3, lambda b, k: None, lambda keep: None, inline_gather=lambda *a, **k: (None, None))
